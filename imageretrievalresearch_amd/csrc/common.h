@@ -1,0 +1,78 @@
+// Shared host/device helpers for libmi355_retrieval (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+namespace mi355 {
+
+// ---- error plumbing: every C-ABI entry returns 0 on success, nonzero + mi355_last_error() text.
+void set_error(const char* fmt, ...);
+enum { OK = 0, ERR_ARG = 1, ERR_HIP = 2, ERR_STATE = 3, ERR_UNSUPPORTED = 4 };
+
+#define MI355_CHECK_HIP(expr)                                                              \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            mi355::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return mi355::ERR_HIP;                                                         \
+        }                                                                                  \
+    } while (0)
+
+#define MI355_REQUIRE(cond, ...)                                                           \
+    do {                                                                                   \
+        if (!(cond)) {                                                                     \
+            mi355::set_error(__VA_ARGS__);                                                 \
+            return mi355::ERR_ARG;                                                         \
+        }                                                                                  \
+    } while (0)
+
+#define MI355_LAUNCH_CHECK() MI355_CHECK_HIP(hipGetLastError())
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// ---- bf16 <-> f32 bit helpers (device).  Plain casts so NaN stays NaN (v_cvt_pk_bf16_f32).
+typedef unsigned short bf16_t;  // storage type for bf16 tensors across the library
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __hip_bfloat16 h = __float2bfloat16(f);  // round-to-nearest-even
+    return *reinterpret_cast<bf16_t*>(&h);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// activation codes shared by the conv / GEMM epilogues
+enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_RELU6 = 3, ACT_GELU = 4, ACT_SIGMOID = 5 };
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+    switch (act) {
+        case ACT_SILU: return silu_f(x);
+        case ACT_RELU: return fmaxf(x, 0.f);
+        case ACT_RELU6: return fminf(fmaxf(x, 0.f), 6.f);
+        case ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+        case ACT_SIGMOID: return sigmoid_f(x);
+        default: return x;
+    }
+}
+
+// wave64 reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace mi355

@@ -1,0 +1,690 @@
+// Rank half of the hot path: row normalisation, exact-f32 MFMA cosine GEMM, top-k selection,
+// shard merge, pair cosine, ContrastiveLoss, hit counting.  gfx950 only.
+//
+// Reference semantics: torch.nn.CosineSimilarity(dim=1, eps=1e-6) + torch.topk as called at
+// train/train.py:250-251 (see include/mi355_retrieval.h).  Everything here is fp32: the GEMM runs on
+// v_mfma_f32_32x32x2_f32, which is bit-for-bit an fmaf chain (no reduced-precision path), so an
+// index can only differ from the CPU oracle where two scores are closer than fp32 summation noise.
+#include "common.h"
+#include "../../include/mi355_retrieval.h"
+
+#include <limits.h>
+#include <math.h>
+
+namespace mi355 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef long long i64;
+
+// =====================================================================================
+// row norms
+// =====================================================================================
+// One wave per row; float4 loads when dim % 4 == 0 and rows are 16-B aligned.
+template <bool WRITE_ROWS>
+__global__ __launch_bounds__(256) void k_row_norm(const float* __restrict__ in, float* __restrict__ out,
+                                                  float* __restrict__ inv, i64 rows, int dim, float eps,
+                                                  int vec) {
+    const int lane = threadIdx.x & 63;
+    const i64 row = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* x = in + row * dim;
+    float ss = 0.f;
+    if (vec) {
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+        for (int i = lane; i < dim / 4; i += 64) {
+            f32x4 v = x4[i];
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+    } else {
+        for (int i = lane; i < dim; i += 64) ss += x[i] * x[i];
+    }
+    ss = wave_sum(ss);
+    const float r = 1.0f / fmaxf(sqrtf(ss), eps);
+    if (inv != nullptr && lane == 0) inv[row] = r;
+    if (WRITE_ROWS) {
+        float* y = out + row * dim;
+        if (vec) {
+            const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+            f32x4* y4 = reinterpret_cast<f32x4*>(y);
+            for (int i = lane; i < dim / 4; i += 64) {
+                f32x4 v = x4[i];
+                v.x *= r; v.y *= r; v.z *= r; v.w *= r;
+                y4[i] = v;
+            }
+        } else {
+            for (int i = lane; i < dim; i += 64) y[i] = x[i] * r;
+        }
+    }
+}
+
+static inline int vec_ok(const void* p, int dim) { return (dim % 4 == 0) && (((uintptr_t)p & 15) == 0); }
+
+// =====================================================================================
+// cosine GEMM:  S[q][g] = sum_d Qn[q][d] * Gal[g][d] * (ginv ? ginv[g] : 1)
+// =====================================================================================
+// Block = 4 waves as 2(M) x 2(N); wave tile = (MT*32) queries x 64 gallery rows; block tile =
+// (64*MT) x 128, BK = 32.  Both operands are "row x k-contiguous", so they share one LDS image:
+// [rows][36] floats (32 + 4 pad: ds_read_b128 of 16 distinct rows is bank-conflict free).
+// Per lane a float4 at k = 8t + 4*(lane>>5) feeds four 32x32x2 k-steps; A and B use the same k
+// permutation, which only reorders the (exact) fma chain.
+constexpr int RK_BK = 32;
+constexpr int RK_LD = 36;
+constexpr int RK_BN = 128;
+
+template <int MT, bool VEC>
+__global__ __launch_bounds__(256) void k_cos_gemm(const float* __restrict__ Qn, const float* __restrict__ Gal,
+                                                  const float* __restrict__ ginv, float* __restrict__ S,
+                                                  int Q, i64 G, int D) {
+    constexpr int BM = 64 * MT;
+    constexpr int A_LOADS = BM / 32;      // float4 loads per thread per K-tile for A
+    constexpr int B_LOADS = RK_BN / 32;   // 4
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                          // [2][BM][RK_LD]
+    float* Bs = smem + 2 * BM * RK_LD;         // [2][RK_BN][RK_LD]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const i64 n0 = (i64)blockIdx.x * RK_BN;
+    const int m0 = blockIdx.y * BM;
+
+    const int c4 = tid & 7;    // float4 column within the 32-float K-tile
+    const int r0 = tid >> 3;   // 0..31
+
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    f32x4 ra[A_LOADS], rb[B_LOADS];
+
+    auto load_tile = [&](int k0) {
+        const int k = k0 + c4 * 4;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int row = m0 + r0 + 32 * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < Q) {
+                const float* p = Qn + (i64)row * D + k;
+                if (VEC) {
+                    if (k + 3 < D) v = *reinterpret_cast<const f32x4*>(p);
+                } else {
+                    if (k + 0 < D) v.x = p[0];
+                    if (k + 1 < D) v.y = p[1];
+                    if (k + 2 < D) v.z = p[2];
+                    if (k + 3 < D) v.w = p[3];
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const i64 row = n0 + r0 + 32 * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < G) {
+                const float* p = Gal + row * D + k;
+                if (VEC) {
+                    if (k + 3 < D) v = *reinterpret_cast<const f32x4*>(p);
+                } else {
+                    if (k + 0 < D) v.x = p[0];
+                    if (k + 1 < D) v.y = p[1];
+                    if (k + 2 < D) v.z = p[2];
+                    if (k + 3 < D) v.w = p[3];
+                }
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* a = As + buf * BM * RK_LD;
+        float* b = Bs + buf * RK_BN * RK_LD;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i)
+            *reinterpret_cast<f32x4*>(a + (r0 + 32 * i) * RK_LD + c4 * 4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i)
+            *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * RK_LD + c4 * 4) = rb[i];
+    };
+
+    const int nt = (D + RK_BK - 1) / RK_BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int lr = lane & 31;
+    const int lk = (lane >> 5) * 4;
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) load_tile((t + 1) * RK_BK);
+        const float* a = As + buf * BM * RK_LD + (wm * MT * 32 + lr) * RK_LD + lk;
+        const float* b = Bs + buf * RK_BN * RK_LD + (wn * 64 + lr) * RK_LD + lk;
+#pragma unroll
+        for (int t8 = 0; t8 < 4; ++t8) {
+            f32x4 af[MT], bfr[2];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * RK_LD + t8 * 8);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * RK_LD + t8 * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bfr[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < nt) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C[row = query][col = gallery]; lane: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const i64 col = n0 + wn * 64 + j * 32 + lr;
+        if (col >= G) continue;
+        const float gs = ginv ? ginv[col] : 1.0f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * MT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < Q) S[(i64)row * G + col] = acc[i][j][r] * gs;
+            }
+        }
+    }
+}
+
+// =====================================================================================
+// top-k selection
+// =====================================================================================
+__device__ __forceinline__ bool better(float a, i64 ia, float b, i64 ib) {
+    return (a > b) || (a == b && ia < ib);
+}
+
+constexpr float NEG_INF = -INFINITY;
+constexpr i64 IDX_PAD = LLONG_MAX;
+
+// ---- small k (<= 8): per-thread sorted list in registers, then k rounds of block arg-max.
+// grid = (nchunk, Q).  Input row q: vals[q*in_stride + j], j in [0,rowlen); implicit index j (+offset)
+// when idxs == nullptr.  Output: out[(q*nchunk + chunk)*k + r].
+template <int K>
+__global__ __launch_bounds__(256) void k_topk_small(const float* __restrict__ vals, const i64* __restrict__ idxs,
+                                                    i64 rowlen, i64 in_stride, i64 chunk_len, int k,
+                                                    i64 idx_offset, float* __restrict__ ov, i64* __restrict__ oi) {
+    const int tid = threadIdx.x;
+    const i64 q = blockIdx.y;
+    const i64 c0 = (i64)blockIdx.x * chunk_len;
+    const i64 c1 = min(rowlen, c0 + chunk_len);
+    const float* v = vals + q * in_stride;
+    const i64* ix = idxs ? idxs + q * in_stride : nullptr;
+
+    float lv[K];
+    i64 li[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) { lv[i] = NEG_INF; li[i] = IDX_PAD; }
+
+    for (i64 j = c0 + tid; j < c1; j += 256) {
+        const float x = v[j];
+        const i64 id = ix ? ix[j] : j + idx_offset;
+        if (better(x, id, lv[K - 1], li[K - 1])) {
+            lv[K - 1] = x; li[K - 1] = id;
+#pragma unroll
+            for (int i = K - 1; i > 0; --i) {
+                if (better(lv[i], li[i], lv[i - 1], li[i - 1])) {
+                    float tv = lv[i]; lv[i] = lv[i - 1]; lv[i - 1] = tv;
+                    i64 ti = li[i]; li[i] = li[i - 1]; li[i - 1] = ti;
+                }
+            }
+        }
+    }
+
+    __shared__ float sv[4];
+    __shared__ i64 si[4];
+    const int lane = tid & 63, wave = tid >> 6;
+    float* o_v = ov + (q * gridDim.x + blockIdx.x) * k;
+    i64* o_i = oi + (q * gridDim.x + blockIdx.x) * k;
+    for (int r = 0; r < k; ++r) {
+        float bv = lv[0];
+        i64 bi = li[0];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov2 = __shfl_xor(bv, o, 64);
+            const i64 oi2 = __shfl_xor(bi, o, 64);
+            if (better(ov2, oi2, bv, bi)) { bv = ov2; bi = oi2; }
+        }
+        if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+        __syncthreads();
+        bv = sv[0]; bi = si[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (better(sv[w], si[w], bv, bi)) { bv = sv[w]; bi = si[w]; }
+        if (tid == 0) { o_v[r] = bv; o_i[r] = bi; }
+        // the owner pops its head (indices are unique among real entries; pads never win a real slot)
+        if (li[0] == bi && lv[0] == bv && bi != IDX_PAD) {
+#pragma unroll
+            for (int i = 0; i < K - 1; ++i) { lv[i] = lv[i + 1]; li[i] = li[i + 1]; }
+            lv[K - 1] = NEG_INF; li[K - 1] = IDX_PAD;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- any k <= 1024: bitonic sort of a 2048-element chunk in LDS, keep the first k.
+constexpr int BT_N = 2048;
+__global__ __launch_bounds__(256) void k_topk_bitonic(const float* __restrict__ vals, const i64* __restrict__ idxs,
+                                                      i64 rowlen, i64 in_stride, int k, i64 idx_offset,
+                                                      float* __restrict__ ov, i64* __restrict__ oi) {
+    __shared__ float sv[BT_N];
+    __shared__ i64 si[BT_N];
+    const int tid = threadIdx.x;
+    const i64 q = blockIdx.y;
+    const i64 c0 = (i64)blockIdx.x * BT_N;
+    const float* v = vals + q * in_stride;
+    const i64* ix = idxs ? idxs + q * in_stride : nullptr;
+    for (int j = tid; j < BT_N; j += 256) {
+        const i64 g = c0 + j;
+        if (g < rowlen) {
+            sv[j] = v[g];
+            si[j] = ix ? ix[g] : g + idx_offset;
+        } else {
+            sv[j] = NEG_INF;
+            si[j] = IDX_PAD;
+        }
+    }
+    __syncthreads();
+    for (int size = 2; size <= BT_N; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < BT_N / 2; t += 256) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);  // first half of each size-block sorted descending
+                const float a = sv[lo], b = sv[hi];
+                const i64 ia = si[lo], ib = si[hi];
+                const bool swap = desc ? better(b, ib, a, ia) : better(a, ia, b, ib);
+                if (swap) { sv[lo] = b; sv[hi] = a; si[lo] = ib; si[hi] = ia; }
+            }
+            __syncthreads();
+        }
+    }
+    float* o_v = ov + (q * gridDim.x + blockIdx.x) * k;
+    i64* o_i = oi + (q * gridDim.x + blockIdx.x) * k;
+    for (int j = tid; j < k; j += 256) { o_v[j] = sv[j]; o_i[j] = si[j]; }
+}
+
+// =====================================================================================
+// small ops
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_pair_cosine(const float* __restrict__ a, const float* __restrict__ b,
+                                                     i64 rows, int dim, float eps, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const i64 row = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* x = a + row * dim;
+    const float* y = b + row * dim;
+    float xx = 0.f, yy = 0.f, xy = 0.f;
+    for (int i = lane; i < dim; i += 64) {
+        const float u = x[i], w = y[i];
+        xx += u * u; yy += w * w; xy += u * w;
+    }
+    xx = wave_sum(xx); yy = wave_sum(yy); xy = wave_sum(xy);
+    if (lane == 0) out[row] = xy / (fmaxf(sqrtf(xx), eps) * fmaxf(sqrtf(yy), eps));
+}
+
+// One block of 16 waves; wave w owns rows w, w+16, ... and adds them in that order, then thread 0
+// adds the 16 wave partials in wave order: the result is a fixed function of the inputs.
+__global__ __launch_bounds__(1024) void k_contrastive(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                      i64 rows, int dim, float label, float margin, int mean,
+                                                      float* __restrict__ out, float* __restrict__ per_row) {
+    __shared__ float part[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc = 0.f;
+    for (i64 r = wave; r < rows; r += 16) {
+        const float* x = f1 + r * dim;
+        const float* y = f2 + r * dim;
+        float d = 0.f;
+        for (int i = lane; i < dim; i += 64) {
+            const float t = y[i] - x[i];
+            d += t * t;
+        }
+        d = wave_sum(d);
+        const float h = fmaxf(margin - sqrtf(d + 1e-9f), 0.f);
+        const float l = 0.5f * (label * d + (1.0f - label) * h * h);
+        if (per_row && lane == 0) per_row[r] = l;
+        acc += l;
+    }
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int w = 0; w < 16; ++w) s += part[w];
+        out[0] = mean ? s / (float)rows : s;
+    }
+}
+
+__global__ void k_hit_counts(const i64* __restrict__ idx, i64 Q, int k, const i64* __restrict__ qcls,
+                             const i64* __restrict__ gcls, i64* __restrict__ counts) {
+    const i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    int h1 = 0, h3 = 0;
+    if (q < Q) {
+        const i64 c = qcls[q];
+        h1 = (gcls[idx[q * k]] == c);
+        for (int j = 0; j < min(k, 3); ++j) h3 |= (gcls[idx[q * k + j]] == c);
+    }
+    // integer atomics: order-independent
+    const unsigned long long m1 = __ballot(h1), m3 = __ballot(h3);
+    if ((threadIdx.x & 63) == 0) {
+        if (m1) atomicAdd((unsigned long long*)&counts[0], (unsigned long long)__popcll(m1));
+        if (m3) atomicAdd((unsigned long long*)&counts[1], (unsigned long long)__popcll(m3));
+    }
+}
+
+__global__ void k_distinct_topn(const i64* __restrict__ idx, const float* __restrict__ val, i64 Q, int k,
+                                const i64* __restrict__ gcls, int n, i64* __restrict__ ocls,
+                                i64* __restrict__ oidx, float* __restrict__ oval) {
+    const i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    i64 seen[8];
+    int ns = 0;
+    for (int j = 0; j < n; ++j) { ocls[q * n + j] = -1; oidx[q * n + j] = -1; oval[q * n + j] = NAN; }
+    for (int j = 0; j < k && ns < n; ++j) {
+        const i64 g = idx[q * k + j];
+        const i64 c = gcls[g];
+        bool dup = false;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) dup |= (s < ns && seen[s] == c);
+        if (!dup) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if (s == ns) seen[s] = c;
+            ocls[q * n + ns] = c; oidx[q * n + ns] = g; oval[q * n + ns] = val[q * k + j];
+            ++ns;
+        }
+    }
+}
+
+// =====================================================================================
+// host drivers
+// =====================================================================================
+constexpr int SMALL_K = 8;
+constexpr int LARGE_K = 1024;
+constexpr i64 SMALL_CHUNK = 8192;
+
+struct TopkPlan {
+    bool small;
+    i64 nchunk1;        // level-1 chunks per row
+    size_t cand_elems;  // elements per ping/pong candidate buffer (per query row) * Q
+};
+
+static i64 level1_chunks(i64 G, int k) { return k <= SMALL_K ? cdiv(G, SMALL_CHUNK) : cdiv(G, BT_N); }
+
+static size_t topk_ws_bytes(i64 Q, i64 G, int k) {
+    const i64 per_row = level1_chunks(G, k) * k;
+    // two ping-pong buffers of (val f32 + idx i64)
+    return 2 * align_up((size_t)Q * per_row * (sizeof(float) + sizeof(i64)), 256) + 256;
+}
+
+template <int K>
+static void launch_small(const float* v, const i64* ix, i64 rowlen, i64 in_stride, i64 chunk_len, int k,
+                         i64 off, float* ov, i64* oi, i64 nchunk, i64 Q, hipStream_t st) {
+    hipLaunchKernelGGL((k_topk_small<K>), dim3((unsigned)nchunk, (unsigned)Q), dim3(256), 0, st, v, ix, rowlen,
+                       in_stride, chunk_len, k, off, ov, oi);
+}
+static void dispatch_small(const float* v, const i64* ix, i64 rowlen, i64 in_stride, i64 chunk_len, int k,
+                           i64 off, float* ov, i64* oi, i64 nchunk, i64 Q, hipStream_t st) {
+    if (k <= 1) launch_small<1>(v, ix, rowlen, in_stride, chunk_len, k, off, ov, oi, nchunk, Q, st);
+    else if (k <= 2) launch_small<2>(v, ix, rowlen, in_stride, chunk_len, k, off, ov, oi, nchunk, Q, st);
+    else if (k <= 4) launch_small<4>(v, ix, rowlen, in_stride, chunk_len, k, off, ov, oi, nchunk, Q, st);
+    else launch_small<8>(v, ix, rowlen, in_stride, chunk_len, k, off, ov, oi, nchunk, Q, st);
+}
+
+// Select top-k of each row of vals[Q][rowlen] (implicit or explicit indices) into out_val/out_idx [Q][k].
+static int topk_select(const float* vals, const i64* idxs, i64 Q, i64 rowlen, i64 in_stride, int k, i64 idx_offset,
+                       float* out_val, i64* out_idx, void* ws, size_t ws_bytes, hipStream_t st) {
+    MI355_REQUIRE(k >= 1 && k <= LARGE_K, "top-k: k=%d outside [1,%d]", k, LARGE_K);
+    MI355_REQUIRE(k <= rowlen, "top-k: k=%d exceeds row length %lld", k, (long long)rowlen);
+    MI355_REQUIRE(Q >= 1 && Q <= 65535 * 16, "top-k: Q=%lld out of range", (long long)Q);
+    MI355_REQUIRE(ws_bytes >= topk_ws_bytes(Q, rowlen, k), "top-k: workspace %zu < %zu bytes", ws_bytes,
+                  topk_ws_bytes(Q, rowlen, k));
+    const i64 per_row_max = level1_chunks(rowlen, k) * k;
+    const size_t half = align_up((size_t)Q * per_row_max * (sizeof(float) + sizeof(i64)), 256);
+    char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    float* cv[2];
+    i64* ci[2];
+    for (int b = 0; b < 2; ++b) {
+        ci[b] = (i64*)(base + b * half);
+        cv[b] = (float*)(base + b * half + (size_t)Q * per_row_max * sizeof(i64));
+    }
+    // grid.y limit: split Q into slabs of 65535 rows
+    for (i64 qs = 0; qs < Q; qs += 65535) {
+        const i64 qn = (Q - qs < 65535) ? Q - qs : 65535;
+        const float* v = vals + qs * in_stride;
+        const i64* ix = idxs ? idxs + qs * in_stride : nullptr;
+        i64 len = rowlen, stride = in_stride;
+        i64 off = idx_offset;
+        int cur = 0;
+        while (true) {
+            const bool small = (k <= SMALL_K);
+            const i64 chunk = small ? SMALL_CHUNK : BT_N;
+            const i64 nchunk = cdiv(len, chunk);
+            const bool last = (nchunk == 1);
+            float* ovp = last ? out_val + qs * k : cv[cur];
+            i64* oip = last ? out_idx + qs * k : ci[cur];
+            if (small) dispatch_small(v, ix, len, stride, chunk, k, off, ovp, oip, nchunk, qn, st);
+            else hipLaunchKernelGGL(k_topk_bitonic, dim3((unsigned)nchunk, (unsigned)qn), dim3(256), 0, st, v, ix,
+                                    len, stride, k, off, ovp, oip);
+            MI355_LAUNCH_CHECK();
+            if (last) break;
+            v = cv[cur]; ix = ci[cur];
+            len = nchunk * k; stride = len; off = 0;
+            cur ^= 1;
+        }
+    }
+    return OK;
+}
+
+static i64 query_block(i64 Q, i64 G) {
+    // keep the score slab S[qb][G] around <= 1 GiB, in multiples of 256 queries
+    i64 qb = ((i64)1 << 28) / (G > 0 ? G : 1);
+    qb = qb / 256 * 256;
+    if (qb < 256) qb = 256;
+    return qb < Q ? qb : Q;
+}
+
+struct RankWs {
+    float* qn; float* ginv; float* S; void* topk; size_t topk_bytes; size_t total;
+};
+static RankWs carve(void* ws, i64 Q, i64 G, int D, int k, bool need_ginv, bool need_S = true) {
+    RankWs r{};
+    const i64 qb = query_block(Q, G);
+    size_t off = 0;
+    char* base = ws ? (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255) : nullptr;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
+    r.qn = (float*)take((size_t)Q * D * sizeof(float));
+    r.ginv = (float*)take(need_ginv ? (size_t)G * sizeof(float) : 0);
+    r.S = (float*)take(need_S ? (size_t)qb * G * sizeof(float) : 0);
+    r.topk_bytes = k > 0 ? topk_ws_bytes(qb, G, k) : 0;
+    r.topk = take(r.topk_bytes);
+    r.total = off + 256;
+    return r;
+}
+
+template <int MT, bool VEC>
+static int launch_gemm(const float* qn, const float* gal, const float* ginv, float* S, int Q, i64 G, int D,
+                       hipStream_t st) {
+    constexpr int BM = 64 * MT;
+    const size_t lds = (size_t)2 * (BM + RK_BN) * RK_LD * sizeof(float);
+    static bool attr_done = false;  // per instantiation
+    if (!attr_done) {
+        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_cos_gemm<MT, VEC>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    dim3 grid((unsigned)cdiv(G, RK_BN), (unsigned)cdiv(Q, BM));
+    hipLaunchKernelGGL((k_cos_gemm<MT, VEC>), grid, dim3(256), lds, st, qn, gal, ginv, S, Q, G, D);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
+static int cos_gemm(const float* qn, const float* gal, const float* ginv, float* S, i64 Q, i64 G, int D,
+                    hipStream_t st) {
+    const bool vec = vec_ok(qn, D) && vec_ok(gal, D);
+    const int q = (int)Q;
+    if (Q > 128) return vec ? launch_gemm<4, true>(qn, gal, ginv, S, q, G, D, st) : launch_gemm<4, false>(qn, gal, ginv, S, q, G, D, st);
+    if (Q > 64) return vec ? launch_gemm<2, true>(qn, gal, ginv, S, q, G, D, st) : launch_gemm<2, false>(qn, gal, ginv, S, q, G, D, st);
+    return vec ? launch_gemm<1, true>(qn, gal, ginv, S, q, G, D, st) : launch_gemm<1, false>(qn, gal, ginv, S, q, G, D, st);
+}
+
+static int check_rank_args(const float* queries, i64 Q, const float* gallery, i64 G, int dim) {
+    MI355_REQUIRE(queries && gallery, "rank: null queries/gallery pointer");
+    MI355_REQUIRE(Q >= 1, "rank: Q=%lld must be >= 1", (long long)Q);
+    MI355_REQUIRE(G >= 1, "rank: G=%lld must be >= 1", (long long)G);
+    MI355_REQUIRE(dim >= 1, "rank: dim=%d must be >= 1", dim);
+    return OK;
+}
+
+}  // namespace mi355
+
+using namespace mi355;
+
+extern "C" {
+
+int mi355_l2_normalize_rows(const float* in, float* out, int64_t rows, int dim, float eps, void* stream) {
+    MI355_REQUIRE(in && out, "l2_normalize_rows: null pointer");
+    MI355_REQUIRE(rows >= 0 && dim >= 1, "l2_normalize_rows: bad shape rows=%lld dim=%d", (long long)rows, dim);
+    if (rows == 0) return OK;
+    const int vec = vec_ok(in, dim) && vec_ok(out, dim);
+    hipLaunchKernelGGL((k_row_norm<true>), dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, in, out,
+                       (float*)nullptr, (i64)rows, dim, eps, vec);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
+size_t mi355_rank_workspace_bytes(int64_t Q, int64_t G, int dim, int k) {
+    if (Q < 1 || G < 1) return 0;
+    if (dim <= 0) return topk_ws_bytes(Q, G, k < 1 ? 1 : k) + 256;
+    return carve(nullptr, Q, G, dim, k, true).total;
+}
+
+int mi355_cosine_scores(const float* queries, int64_t Q, const float* gallery, int64_t G, int dim,
+                        int gallery_is_normalized, float eps, float* out, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+    if (int e = check_rank_args(queries, Q, gallery, G, dim)) return e;
+    MI355_REQUIRE(out, "cosine_scores: null output");
+    hipStream_t st = (hipStream_t)stream;
+    RankWs w = carve(workspace, Q, G, dim, 0, !gallery_is_normalized, false);
+    MI355_REQUIRE(workspace && workspace_bytes >= w.total, "cosine_scores: workspace %zu < %zu bytes",
+                  workspace_bytes, w.total);
+    const int vq = vec_ok(queries, dim) && vec_ok(w.qn, dim);
+    hipLaunchKernelGGL((k_row_norm<true>), dim3((unsigned)cdiv(Q, 4)), dim3(256), 0, st, queries, w.qn,
+                       (float*)nullptr, (i64)Q, dim, eps, vq);
+    MI355_LAUNCH_CHECK();
+    if (!gallery_is_normalized) {
+        hipLaunchKernelGGL((k_row_norm<false>), dim3((unsigned)cdiv(G, 4)), dim3(256), 0, st, gallery,
+                           (float*)nullptr, w.ginv, (i64)G, dim, eps, vec_ok(gallery, dim));
+        MI355_LAUNCH_CHECK();
+    }
+    const float* ginv = gallery_is_normalized ? nullptr : w.ginv;
+    for (i64 qs = 0; qs < Q; qs += 256 * 64) {  // grid.y stays small
+        const i64 qn = (Q - qs < 256 * 64) ? Q - qs : 256 * 64;
+        if (int e = cos_gemm(w.qn + qs * dim, gallery, ginv, out + qs * G, qn, G, dim, st)) return e;
+    }
+    return OK;
+}
+
+int mi355_rank_topk(const float* queries, int64_t Q, const float* gallery, int64_t G, int dim,
+                    int gallery_is_normalized, int k, float eps, int64_t idx_offset, float* out_val,
+                    int64_t* out_idx, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int e = check_rank_args(queries, Q, gallery, G, dim)) return e;
+    MI355_REQUIRE(out_val && out_idx, "rank_topk: null output");
+    MI355_REQUIRE(k >= 1 && k <= LARGE_K, "rank_topk: k=%d outside [1,%d]", k, LARGE_K);
+    MI355_REQUIRE(k <= G, "rank_topk: k=%d exceeds gallery rows %lld", k, (long long)G);
+    hipStream_t st = (hipStream_t)stream;
+    RankWs w = carve(workspace, Q, G, dim, k, !gallery_is_normalized);
+    MI355_REQUIRE(workspace && workspace_bytes >= w.total, "rank_topk: workspace %zu < %zu bytes", workspace_bytes,
+                  w.total);
+    const int vq = vec_ok(queries, dim) && vec_ok(w.qn, dim);
+    hipLaunchKernelGGL((k_row_norm<true>), dim3((unsigned)cdiv(Q, 4)), dim3(256), 0, st, queries, w.qn,
+                       (float*)nullptr, (i64)Q, dim, eps, vq);
+    MI355_LAUNCH_CHECK();
+    if (!gallery_is_normalized) {
+        hipLaunchKernelGGL((k_row_norm<false>), dim3((unsigned)cdiv(G, 4)), dim3(256), 0, st, gallery,
+                           (float*)nullptr, w.ginv, (i64)G, dim, eps, vec_ok(gallery, dim));
+        MI355_LAUNCH_CHECK();
+    }
+    const float* ginv = gallery_is_normalized ? nullptr : w.ginv;
+    const i64 qb = query_block(Q, G);
+    for (i64 qs = 0; qs < Q; qs += qb) {
+        const i64 qn = (Q - qs < qb) ? Q - qs : qb;
+        if (int e = cos_gemm(w.qn + qs * dim, gallery, ginv, w.S, qn, G, dim, st)) return e;
+        if (int e = topk_select(w.S, nullptr, qn, G, G, k, idx_offset, out_val + qs * k, (i64*)out_idx + qs * k,
+                                w.topk, w.topk_bytes, st))
+            return e;
+    }
+    return OK;
+}
+
+int mi355_topk_rows(const float* scores, int64_t Q, int64_t G, int k, int64_t idx_offset, float* out_val,
+                    int64_t* out_idx, void* workspace, size_t workspace_bytes, void* stream) {
+    MI355_REQUIRE(scores && out_val && out_idx, "topk_rows: null pointer");
+    MI355_REQUIRE(Q >= 1 && G >= 1, "topk_rows: bad shape Q=%lld G=%lld", (long long)Q, (long long)G);
+    MI355_REQUIRE(workspace, "topk_rows: null workspace");
+    return topk_select(scores, nullptr, Q, G, G, k, idx_offset, out_val, (i64*)out_idx, workspace, workspace_bytes,
+                       (hipStream_t)stream);
+}
+
+int mi355_merge_topk(const float* cand_val, const int64_t* cand_idx, int64_t Q, int ncand, int k, float* out_val,
+                     int64_t* out_idx, void* workspace, size_t workspace_bytes, void* stream) {
+    MI355_REQUIRE(cand_val && cand_idx && out_val && out_idx, "merge_topk: null pointer");
+    MI355_REQUIRE(Q >= 1 && ncand >= 1, "merge_topk: bad shape Q=%lld ncand=%d", (long long)Q, ncand);
+    MI355_REQUIRE(workspace, "merge_topk: null workspace");
+    return topk_select(cand_val, (const i64*)cand_idx, Q, ncand, ncand, k, 0, out_val, (i64*)out_idx, workspace,
+                       workspace_bytes, (hipStream_t)stream);
+}
+
+int mi355_pair_cosine(const float* a, const float* b, int64_t rows, int dim, float eps, float* out, void* stream) {
+    MI355_REQUIRE(a && b && out, "pair_cosine: null pointer");
+    MI355_REQUIRE(rows >= 0 && dim >= 1, "pair_cosine: bad shape");
+    if (rows == 0) return OK;
+    hipLaunchKernelGGL(k_pair_cosine, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, a, b,
+                       (i64)rows, dim, eps, out);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
+int mi355_contrastive_loss(const float* fm1, const float* fm2, int64_t rows, int dim, float label, float margin,
+                           int mean, float* out, float* per_row, void* stream) {
+    MI355_REQUIRE(fm1 && fm2 && out, "contrastive_loss: null pointer");
+    MI355_REQUIRE(rows >= 1 && dim >= 1, "contrastive_loss: bad shape rows=%lld dim=%d", (long long)rows, dim);
+    hipLaunchKernelGGL(k_contrastive, dim3(1), dim3(1024), 0, (hipStream_t)stream, fm1, fm2, (i64)rows, dim, label,
+                       margin, mean, out, per_row);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
+int mi355_hit_counts(const int64_t* idx, int64_t Q, int k, const int64_t* query_cls, const int64_t* gallery_cls,
+                     int64_t* counts, void* stream) {
+    MI355_REQUIRE(idx && query_cls && gallery_cls && counts, "hit_counts: null pointer");
+    MI355_REQUIRE(Q >= 1 && k >= 1, "hit_counts: bad shape");
+    hipLaunchKernelGGL(k_hit_counts, dim3((unsigned)cdiv(Q, 256)), dim3(256), 0, (hipStream_t)stream, (const i64*)idx,
+                       (i64)Q, k, (const i64*)query_cls, (const i64*)gallery_cls, (i64*)counts);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
+int mi355_distinct_class_topn(const int64_t* idx, const float* val, int64_t Q, int k, const int64_t* gallery_cls,
+                              int n, int64_t* out_cls, int64_t* out_idx, float* out_val, void* stream) {
+    MI355_REQUIRE(idx && val && gallery_cls && out_cls && out_idx && out_val, "distinct_class_topn: null pointer");
+    MI355_REQUIRE(Q >= 1 && k >= 1 && n >= 1 && n <= 8, "distinct_class_topn: bad shape (n must be 1..8)");
+    hipLaunchKernelGGL(k_distinct_topn, dim3((unsigned)cdiv(Q, 128)), dim3(128), 0, (hipStream_t)stream,
+                       (const i64*)idx, val, (i64)Q, k, (const i64*)gallery_cls, n, (i64*)out_cls, (i64*)out_idx,
+                       out_val);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
+}  // extern "C"

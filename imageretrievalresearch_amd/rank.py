@@ -1,0 +1,301 @@
+"""Host side of the rank half: cosine similarity, top-k, ContrastiveLoss, retrieval metrics.
+
+Mirrors the torch objects the reference uses (same names, argument meaning, error behaviour) and
+routes the arithmetic to libmi355_retrieval:
+
+* ``CosineSimilarity(dim=1, eps=1e-6)`` ....... train/train.py:73, inference/inference.py:169
+* ``topk(sim, k)`` ............................ train/train.py:251,356 ; notebook raw :238
+* ``cosine_topk(Q, G, k)`` .................... the whole per-query loop train/train.py:249-255 as one call
+* ``ContrastiveLoss(margin)(fm1, fm2, label, mean)`` ... utils/contrastive_loss.py:6-61
+* ``hit_counts`` / ``distinct_class_topn`` .... train/train.py:252-255 ; notebook raw :240-251
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import MI355Error, check, lib, require_cuda, stream_ptr
+
+_EPS = 1e-6
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    require_cuda(t, name)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class _Workspace:
+    """Per-device scratch that only grows; reused across calls (no hipMalloc on the hot path)."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, device, nbytes: int) -> torch.Tensor:
+        b = self.buf.get(device)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self.buf[device] = b
+        return b
+
+
+_ws = _Workspace()
+
+
+def synth_fill(n: int, seed: int, kind: int, device, offset: int = 0) -> torch.Tensor:
+    """Device-side portable generator (bit-identical to ``synth.fill``)."""
+    out = torch.empty(int(n), dtype=torch.float32, device=device)
+    require_cuda(out, "synth_fill output")
+    with torch.cuda.device(out.device):
+        check(lib().mi355_synth_fill(out.data_ptr(), int(n), int(seed), int(offset), int(kind),
+                                     stream_ptr(out.device)))
+    return out
+
+
+def l2_normalize_rows(x: torch.Tensor, eps: float = _EPS, out: torch.Tensor | None = None) -> torch.Tensor:
+    x = _f32c(x, "x")
+    if x.dim() != 2:
+        raise MI355Error(f"l2_normalize_rows expects (rows, dim), got {tuple(x.shape)}")
+    if out is None:
+        out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(lib().mi355_l2_normalize_rows(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], eps,
+                                            stream_ptr(x.device)))
+    return out
+
+
+def _check_qg(q, g):
+    if q.dim() != 2 or g.dim() != 2:
+        raise MI355Error(f"expected (Q,D) queries and (G,D) gallery, got {tuple(q.shape)} and {tuple(g.shape)}")
+    if q.shape[1] != g.shape[1]:
+        raise MI355Error(f"embedding dims differ: {q.shape[1]} vs {g.shape[1]}")
+    if q.device != g.device:
+        raise MI355Error(f"queries on {q.device} but gallery on {g.device}")
+
+
+def cosine_scores(queries: torch.Tensor, gallery: torch.Tensor, eps: float = _EPS,
+                  gallery_is_normalized: bool = False) -> torch.Tensor:
+    """(Q,D) x (G,D) -> (Q,G) fp32 cosine matrix."""
+    q, g = _f32c(queries, "queries"), _f32c(gallery, "gallery")
+    _check_qg(q, g)
+    Q, D = q.shape
+    G = g.shape[0]
+    out = torch.empty((Q, G), dtype=torch.float32, device=q.device)
+    if Q == 0 or G == 0:
+        return out
+    nbytes = lib().mi355_rank_workspace_bytes(Q, G, D, 0)
+    ws = _ws.get(q.device, nbytes)
+    with torch.cuda.device(q.device):
+        check(lib().mi355_cosine_scores(q.data_ptr(), Q, g.data_ptr(), G, D, int(gallery_is_normalized), eps,
+                                        out.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(q.device)))
+    return out
+
+
+def cosine_topk(queries: torch.Tensor, gallery: torch.Tensor, k: int, eps: float = _EPS,
+                gallery_is_normalized: bool = False, idx_offset: int = 0):
+    """All-pairs cosine + top-k: the loop of train/train.py:249-251 as one call.
+
+    Returns (values (Q,k) fp32, indices (Q,k) int64), sorted by descending score; equal scores are
+    ordered by ascending gallery index.  Raises like ``torch.topk`` when k exceeds the gallery size."""
+    q, g = _f32c(queries, "queries"), _f32c(gallery, "gallery")
+    _check_qg(q, g)
+    Q, D = q.shape
+    G = g.shape[0]
+    if k > G or k < 1:
+        raise MI355Error(f"selected index k out of range: k={k}, gallery rows={G}")
+    vals = torch.empty((Q, k), dtype=torch.float32, device=q.device)
+    idx = torch.empty((Q, k), dtype=torch.int64, device=q.device)
+    if Q == 0:
+        return vals, idx
+    nbytes = lib().mi355_rank_workspace_bytes(Q, G, D, k)
+    ws = _ws.get(q.device, nbytes)
+    with torch.cuda.device(q.device):
+        check(lib().mi355_rank_topk(q.data_ptr(), Q, g.data_ptr(), G, D, int(gallery_is_normalized), k, eps,
+                                    int(idx_offset), vals.data_ptr(), idx.data_ptr(), ws.data_ptr(), ws.numel(),
+                                    stream_ptr(q.device)))
+    return vals, idx
+
+
+def topk(scores: torch.Tensor, k: int, idx_offset: int = 0):
+    """``torch.topk(sim, k)`` over the last dim of a 1-D or 2-D fp32 score tensor."""
+    squeeze = scores.dim() == 1
+    s = _f32c(scores.unsqueeze(0) if squeeze else scores, "scores")
+    if s.dim() != 2:
+        raise MI355Error(f"topk expects a 1-D or 2-D tensor, got {tuple(scores.shape)}")
+    Q, G = s.shape
+    if k > G or k < 1:
+        raise MI355Error(f"selected index k out of range: k={k}, row length={G}")
+    vals = torch.empty((Q, k), dtype=torch.float32, device=s.device)
+    idx = torch.empty((Q, k), dtype=torch.int64, device=s.device)
+    if Q:
+        nbytes = lib().mi355_rank_workspace_bytes(Q, G, 0, k)
+        ws = _ws.get(s.device, nbytes)
+        with torch.cuda.device(s.device):
+            check(lib().mi355_topk_rows(s.data_ptr(), Q, G, k, int(idx_offset), vals.data_ptr(), idx.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), stream_ptr(s.device)))
+    return (vals[0], idx[0]) if squeeze else (vals, idx)
+
+
+def merge_topk(cand_val: torch.Tensor, cand_idx: torch.Tensor, k: int):
+    """Merge (Q, ncand) candidate lists (e.g. all-gathered per-shard top-k) into the global top-k."""
+    v = _f32c(cand_val, "cand_val")
+    require_cuda(cand_idx, "cand_idx")
+    i = cand_idx.to(torch.int64).contiguous()
+    if v.shape != i.shape or v.dim() != 2:
+        raise MI355Error(f"merge_topk expects matching (Q, ncand) tensors, got {tuple(v.shape)} / {tuple(i.shape)}")
+    Q, n = v.shape
+    if k > n or k < 1:
+        raise MI355Error(f"selected index k out of range: k={k}, candidates={n}")
+    vals = torch.empty((Q, k), dtype=torch.float32, device=v.device)
+    idx = torch.empty((Q, k), dtype=torch.int64, device=v.device)
+    if Q:
+        nbytes = lib().mi355_rank_workspace_bytes(Q, n, 0, k)
+        ws = _ws.get(v.device, nbytes)
+        with torch.cuda.device(v.device):
+            check(lib().mi355_merge_topk(v.data_ptr(), i.data_ptr(), Q, n, k, vals.data_ptr(), idx.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), stream_ptr(v.device)))
+    return vals, idx
+
+
+def pair_cosine(a: torch.Tensor, b: torch.Tensor, eps: float = _EPS) -> torch.Tensor:
+    """Row-wise cos(a[i], b[i]) — inference/inference.py:226."""
+    a, b = _f32c(a, "a"), _f32c(b, "b")
+    if a.shape != b.shape or a.dim() != 2:
+        raise MI355Error(f"pair_cosine expects two (B,D) tensors, got {tuple(a.shape)} / {tuple(b.shape)}")
+    out = torch.empty((a.shape[0],), dtype=torch.float32, device=a.device)
+    if a.shape[0]:
+        with torch.cuda.device(a.device):
+            check(lib().mi355_pair_cosine(a.data_ptr(), b.data_ptr(), a.shape[0], a.shape[1], eps, out.data_ptr(),
+                                          stream_ptr(a.device)))
+    return out
+
+
+class CosineSimilarity(torch.nn.Module):
+    """``torch.nn.CosineSimilarity(dim=1, eps)`` for the two call shapes on the hot path:
+    (1,D) vs (G,D) -> (G,)   [train/train.py:250]   and   (B,D) vs (B,D) -> (B,)   [inference.py:226]."""
+
+    def __init__(self, dim: int = 1, eps: float = _EPS):
+        super().__init__()
+        if dim != 1:
+            raise MI355Error("only dim=1 (the reference's setting) is implemented")
+        self.dim, self.eps = dim, eps
+
+    def forward(self, x1: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+        if x1.dim() != 2 or x2.dim() != 2:
+            raise MI355Error(f"CosineSimilarity expects 2-D inputs, got {tuple(x1.shape)} / {tuple(x2.shape)}")
+        if x1.shape == x2.shape and x1.shape[0] != 1:
+            return pair_cosine(x1, x2, self.eps)
+        if x1.shape[0] == 1:
+            return cosine_scores(x1, x2, self.eps)[0]
+        if x2.shape[0] == 1:
+            return cosine_scores(x2, x1, self.eps)[0]
+        raise MI355Error(f"unsupported broadcast {tuple(x1.shape)} vs {tuple(x2.shape)}")
+
+
+class ContrastiveLoss(torch.nn.Module):
+    """utils/contrastive_loss.py:6-61, forward only (the inference loop calls it under no_grad,
+    inference/inference.py:193-204)."""
+
+    def __init__(self, margin):
+        super().__init__()
+        self.margin, self.eps = margin, 1e-9
+
+    def forward(self, fm1, fm2, label, mean=True):
+        a, b = _f32c(fm1, "fm1"), _f32c(fm2, "fm2")
+        if a.shape != b.shape or a.dim() != 2:
+            raise MI355Error(f"ContrastiveLoss expects two (B,D) tensors, got {tuple(a.shape)} / {tuple(b.shape)}")
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device):
+            check(lib().mi355_contrastive_loss(a.data_ptr(), b.data_ptr(), a.shape[0], a.shape[1], float(label),
+                                               float(self.margin), int(bool(mean)), out.data_ptr(), None,
+                                               stream_ptr(a.device)))
+        return out
+
+
+def hit_counts(idx: torch.Tensor, query_cls: torch.Tensor, gallery_cls: torch.Tensor):
+    """train/train.py:252-255 -> (top1_hits, top3_hits) as a device int64[2] tensor (no sync)."""
+    require_cuda(idx, "idx")
+    idx = idx.to(torch.int64).contiguous()
+    qc = query_cls.to(idx.device, torch.int64).contiguous()
+    gc = gallery_cls.to(idx.device, torch.int64).contiguous()
+    if idx.dim() != 2 or qc.shape[0] != idx.shape[0]:
+        raise MI355Error("hit_counts expects idx (Q,k) and query_cls (Q,)")
+    counts = torch.zeros(2, dtype=torch.int64, device=idx.device)
+    if idx.shape[0]:
+        with torch.cuda.device(idx.device):
+            check(lib().mi355_hit_counts(idx.data_ptr(), idx.shape[0], idx.shape[1], qc.data_ptr(), gc.data_ptr(),
+                                         counts.data_ptr(), stream_ptr(idx.device)))
+    return counts
+
+
+def distinct_class_topn(idx: torch.Tensor, val: torch.Tensor, gallery_cls: torch.Tensor, n: int = 3):
+    """Notebook raw :240-251: first n distinct classes along each ranked list."""
+    require_cuda(idx, "idx")
+    idx = idx.to(torch.int64).contiguous()
+    val = _f32c(val, "val")
+    gc = gallery_cls.to(idx.device, torch.int64).contiguous()
+    Q, k = idx.shape
+    oc = torch.empty((Q, n), dtype=torch.int64, device=idx.device)
+    oi = torch.empty((Q, n), dtype=torch.int64, device=idx.device)
+    ov = torch.empty((Q, n), dtype=torch.float32, device=idx.device)
+    if Q:
+        with torch.cuda.device(idx.device):
+            check(lib().mi355_distinct_class_topn(idx.data_ptr(), val.data_ptr(), Q, k, gc.data_ptr(), n,
+                                                  oc.data_ptr(), oi.data_ptr(), ov.data_ptr(),
+                                                  stream_ptr(idx.device)))
+    return oc, oi, ov
+
+
+class Gallery:
+    """Resident gallery: rows are L2-normalised once when added and stay in HBM as fp32 (SURVEY §8e:
+    the gallery is *born* on the GPU that embedded it).  ``search`` is then one fused call per query
+    batch instead of the reference's per-query cosine + topk pair."""
+
+    def __init__(self, dim: int, device, capacity: int = 0, eps: float = _EPS):
+        self.dim, self.device, self.eps = int(dim), torch.device(device), eps
+        self.rows = 0
+        self._buf = torch.empty((max(capacity, 0), self.dim), dtype=torch.float32, device=self.device)
+        self.labels = None
+
+    def _reserve(self, n):
+        if n > self._buf.shape[0]:
+            cap = max(n, int(self._buf.shape[0] * 1.5) + 1024)
+            nb = torch.empty((cap, self.dim), dtype=torch.float32, device=self.device)
+            nb[: self.rows].copy_(self._buf[: self.rows])
+            self._buf = nb
+
+    def add(self, embeddings: torch.Tensor, labels: torch.Tensor | None = None):
+        e = _f32c(embeddings, "embeddings")
+        if e.dim() != 2 or e.shape[1] != self.dim:
+            raise MI355Error(f"gallery rows must be (n,{self.dim}), got {tuple(e.shape)}")
+        n = e.shape[0]
+        self._reserve(self.rows + n)
+        if n:
+            l2_normalize_rows(e, self.eps, out=self._buf[self.rows: self.rows + n])
+        if labels is not None:
+            lab = labels.to(self.device, torch.int64)
+            self.labels = lab if self.labels is None else torch.cat([self.labels, lab])
+        self.rows += n
+        return self
+
+    @property
+    def data(self) -> torch.Tensor:
+        return self._buf[: self.rows]
+
+    def __len__(self):
+        return self.rows
+
+    def search(self, queries: torch.Tensor, k: int, idx_offset: int = 0):
+        return cosine_topk(queries, self.data, k, self.eps, gallery_is_normalized=True, idx_offset=idx_offset)
+
+
+def retrieval_metrics(queries, positives, query_cls, gallery_cls=None, k: int = 3):
+    """The rank loop of inference/inference.py:223-245 with the pinned semantics of train/train.py:
+    mean pair cosine, top-1 and top-3 accuracy of ``queries`` against the ``positives`` gallery."""
+    gallery_cls = query_cls if gallery_cls is None else gallery_cls
+    vals, idx = cosine_topk(queries, positives, k)
+    counts = hit_counts(idx, query_cls, gallery_cls)
+    pos = pair_cosine(queries, positives) if queries.shape == positives.shape else None
+    n = queries.shape[0]
+    return {"top1": counts[0].item() / n, "top3": counts[1].item() / n,
+            "scores": None if pos is None else pos.mean().item(), "topk_vals": vals, "topk_inds": idx}

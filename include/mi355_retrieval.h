@@ -1,0 +1,165 @@
+/*
+ * libmi355_retrieval — C ABI of the MI355X-native embed-then-rank hot path.
+ *
+ * Drop-in boundary.  The reference (vitasoftAI/ImageRetrievalResearch) has no
+ * FFI: its "operator interface" for this path is the timm model object plus a handful of torch
+ * calls.  Each entry point below names the reference call it replaces (file:line relative to the
+ * reference checkout).  Plain pointers and sizes only; no torch types.  All pointers are DEVICE
+ * pointers on the current HIP device unless a parameter says "host".  `stream` is a hipStream_t
+ * passed as void* (NULL = the null stream); every launch goes on that stream and nothing here
+ * synchronises, so torch's `.item()` / `.cpu()` order correctly behind it.
+ *
+ * Error model: every function returns 0 on success, nonzero otherwise, and never aborts;
+ * mi355_last_error() returns a thread-local message for the last failure.
+ *
+ * The Python host side (imageretrievalresearch_amd/) binds exactly these symbols via ctypes; the
+ * binding a reference maintainer would add is shown in INTEGRATION.md.
+ */
+#ifndef MI355_RETRIEVAL_H
+#define MI355_RETRIEVAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_ABI_VERSION 1
+
+/* ------------------------------------------------------------------ library / errors */
+int mi355_abi_version(void);
+const char* mi355_last_error(void);
+/* Number of visible HIP devices (0 when there is no GPU); never fails. */
+int mi355_device_count(void);
+
+/* ------------------------------------------------------------------ synthetic data
+ * Portable counter-based generator, bit-identical to imageretrievalresearch_amd/synth.py.
+ * kind 0 = uniform [0,1), 1 = unit normal (Irwin-Hall 4).  out[i] = f(seed, offset + i). */
+int mi355_synth_fill(float* out, int64_t n, uint64_t seed, int64_t offset, int kind, void* stream);
+
+/* ------------------------------------------------------------------ rank: cosine + top-k
+ * Replaces torch.nn.CosineSimilarity(dim=1, eps=1e-6) + torch.topk at
+ *   train/train.py:250-251, :345-356 ; inference/inference.py:226-242 ; notebook raw :231-251.
+ * Semantics (pinned): score[q][g] = sum_d (Q[q][d]/max(|Q[q]|,eps)) * (G[g][d]/max(|G[g]|,eps)),
+ * fp32 throughout (exact-f32 MFMA); top-k sorted by descending score, ties -> lower index first. */
+
+/* out[r][:] = in[r][:] / max(||in[r]||_2, eps); in == out allowed.  rows x dim fp32 row-major. */
+int mi355_l2_normalize_rows(const float* in, float* out, int64_t rows, int dim, float eps, void* stream);
+
+/* Bytes of scratch mi355_rank_topk needs for (Q, G, D, k). */
+size_t mi355_rank_workspace_bytes(int64_t Q, int64_t G, int dim, int k);
+
+/* All-pairs cosine + top-k.
+ *   queries  [Q][dim] fp32 (raw, normalised internally)
+ *   gallery  [G][dim] fp32; gallery_is_normalized != 0 promises rows already went through
+ *            mi355_l2_normalize_rows (the resident-gallery fast path), else norms are applied here
+ *   out_val  [Q][k] fp32, out_idx [Q][k] int64 (index into gallery + idx_offset)
+ *   idx_offset: added to every index (global row of this shard's first row)
+ * Errors: k < 1, k > G, Q < 1, dim < 1, workspace too small. */
+int mi355_rank_topk(const float* queries, int64_t Q, const float* gallery, int64_t G, int dim,
+                    int gallery_is_normalized, int k, float eps, int64_t idx_offset,
+                    float* out_val, int64_t* out_idx, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
+/* Scores only: out[Q][G] fp32 cosine matrix (same kernel as above without the selection). */
+int mi355_cosine_scores(const float* queries, int64_t Q, const float* gallery, int64_t G, int dim,
+                        int gallery_is_normalized, float eps, float* out, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* Row-wise top-k of an explicit score matrix scores[Q][G] (torch.topk, train/train.py:251).
+ * workspace: mi355_rank_workspace_bytes(Q, G, 0, k). */
+int mi355_topk_rows(const float* scores, int64_t Q, int64_t G, int k, int64_t idx_offset,
+                    float* out_val, int64_t* out_idx, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
+/* Merge per-shard candidates: cand_val/cand_idx [Q][ncand] (ncand = shards*k, any
+ * order) -> global top-k with the same ordering rule.  Used after the RCCL all-gather. */
+int mi355_merge_topk(const float* cand_val, const int64_t* cand_idx, int64_t Q, int ncand, int k,
+                     float* out_val, int64_t* out_idx, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* Row-wise pair cosine, inference/inference.py:226,229: out[i] = cos(a[i], b[i]). */
+int mi355_pair_cosine(const float* a, const float* b, int64_t rows, int dim, float eps, float* out,
+                      void* stream);
+
+/* utils/contrastive_loss.py:36-61 ContrastiveLoss.forward(fm1, fm2, label, mean):
+ *   dis = sum_d (fm2-fm1)^2 ; 0.5*(label*dis + (1-label)*relu(margin - sqrt(dis+1e-9))^2) ;
+ *   out[0] = mean or sum over rows (deterministic order).  per_row (optional, may be NULL) gets
+ *   the per-row losses. */
+int mi355_contrastive_loss(const float* fm1, const float* fm2, int64_t rows, int dim, float label,
+                           float margin, int mean, float* out, float* per_row, void* stream);
+
+/* Hit counting, train/train.py:252-255: counts[0] += #queries whose class equals the class of
+ * their top-1 result, counts[1] += #queries whose class is among their top-min(3,k).
+ * idx [Q][k] int64 into gallery_cls; counts int64[2] must be zeroed by the caller. */
+int mi355_hit_counts(const int64_t* idx, int64_t Q, int k, const int64_t* query_cls,
+                     const int64_t* gallery_cls, int64_t* counts, void* stream);
+
+/* Notebook variant, inference/training_analysis.ipynb raw :240-251: walk each ranked list and keep
+ * the first n (<= 8) DISTINCT classes.  out_cls/out_idx [Q][n] int64 (-1 padded), out_val [Q][n]. */
+int mi355_distinct_class_topn(const int64_t* idx, const float* val, int64_t Q, int k,
+                              const int64_t* gallery_cls, int n, int64_t* out_cls, int64_t* out_idx,
+                              float* out_val, void* stream);
+
+/* ------------------------------------------------------------------ backbone models
+ * Replaces timm.create_model(name, num_classes=N) and the methods the reference calls on it
+ * (inference/inference.py:102,110,133,146,199-201 ; train/train.py:194-195,288,396 ;
+ *  train/train_efficientnet.py:226,230 ; train/train_vit_triplet.py:354-357).
+ * Names: "efficientnet_b3a" ("efficientnet_b3"), "rexnet_150", "rexnet_200",
+ *        "swin_base_patch4_window7_224".  Input 224x224 (effnet/rexnet accept any H,W multiple of 32).
+ */
+typedef struct mi355_model* mi355_model_t;
+
+/* num_classes: 0 = identity classifier (pooled features out), >0 = Linear head of that width. */
+int mi355_model_create(const char* name, int num_classes, mi355_model_t* out);
+void mi355_model_destroy(mi355_model_t m);
+
+/* Parameter/buffer table in timm-0.4.12 state-dict order.  kind: 0 = trainable parameter,
+ * 1 = float buffer (BN running stats), 2 = int64 buffer (num_batches_tracked, relative_position_index). */
+int mi355_model_num_tensors(mi355_model_t m);
+int mi355_model_tensor_info(mi355_model_t m, int i, const char** name, int* ndim, int64_t shape[4],
+                            int* kind);
+int mi355_model_feature_dim(mi355_model_t m);   /* D: 1536 / 1920 / 2560 / 1024 */
+int mi355_model_num_classes(mi355_model_t m);
+
+/* Hand one state-dict tensor (HOST pointer, fp32, contiguous, numel elements) to the model by its
+ * timm key — the load_state_dict half of inference/inference.py:117-124.  int64 buffers are ignored. */
+int mi355_model_set_tensor(mi355_model_t m, const char* name, const float* host_data, int64_t numel);
+
+/* One-time pack (SURVEY §5 "checkpoint"): fold eval-mode BN into the conv weights, round to bf16,
+ * lay out for the kernels, upload to the current device.  Must be called after the last set_tensor
+ * and again whenever weights change. */
+int mi355_model_pack(mi355_model_t m, void* stream);
+
+/* forward_features: x [B][3][H][W] fp32 NCHW (device) ->
+ *   effnet/rexnet: out [B][D][H/32][W/32] fp32 NCHW (un-pooled, as timm returns it)
+ *   swin:          out [B][D] fp32 (timm's swin forward_features pools)
+ * forward: -> out [B][num_classes] fp32 logits, or [B][D] pooled features when num_classes == 0.
+ * pooled_out (optional, may be NULL): [B][D] fp32 global-average-pooled features (get_fm,
+ * train/train.py:84-103) produced on the way. */
+int mi355_model_forward_features(mi355_model_t m, const float* x, int B, int H, int W, float* out,
+                                 float* pooled_out, void* stream);
+int mi355_model_forward(mi355_model_t m, const float* x, int B, int H, int W, float* out,
+                        float* pooled_out, void* stream);
+
+/* Debug/parity tap: copy the bf16 NHWC activation the executor produced for layer `tap_name`
+ * (e.g. "stem", "blocks.1.0") during the LAST forward into out as fp32 NCHW.  Taps are recorded
+ * only after mi355_model_enable_taps(m, 1). */
+int mi355_model_enable_taps(mi355_model_t m, int enable);
+int mi355_model_read_tap(mi355_model_t m, const char* tap_name, float* out, int64_t out_numel,
+                         int64_t shape[4], void* stream);
+
+/* Algorithmic HBM bytes of one forward at batch B (layer-granular model) and the
+ * MACs; used by bench.py's roofline. */
+int mi355_model_traffic(mi355_model_t m, int B, int H, int W, double* act_bytes, double* weight_bytes,
+                        double* macs);
+
+/* conv_input pre-stem (inference/inference.py:103-105): out = SiLU(Conv2d(3,3,3,1,1,bias=False)(x)),
+ * x/out [B][3][H][W] fp32 NCHW, w [3][3][3][3] fp32 (device). */
+int mi355_conv_input_silu(const float* x, const float* w, int B, int H, int W, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_RETRIEVAL_H */

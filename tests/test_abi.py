@@ -1,0 +1,35 @@
+"""C-ABI surface: the library loads without a GPU and exports exactly what include/*.h declares."""
+import ctypes
+import subprocess
+
+from helpers import header_symbols
+from imageretrievalresearch_amd import _lib
+
+
+def test_header_matches_binding_table():
+    assert header_symbols() == sorted(_lib.PROTOTYPES), "include/mi355_retrieval.h and _lib.PROTOTYPES differ"
+
+
+def test_library_exports_every_declared_symbol():
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in header_symbols():
+        assert hasattr(L, name), f"{name} declared in the header but not exported"
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and "mi355_" in ln}
+    assert set(header_symbols()) <= exported
+
+
+def test_loads_and_reports_version_without_gpu():
+    L = _lib.lib()
+    assert L.mi355_abi_version() == 1
+    assert L.mi355_device_count() >= 0
+    assert isinstance(L.mi355_last_error(), bytes)
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    L = _lib.lib()
+    # bad arguments are rejected before any HIP call, with a message
+    assert L.mi355_rank_topk(None, 1, None, 1, 8, 0, 1, 1e-6, 0, None, None, None, 0, None) != 0
+    assert b"null" in L.mi355_last_error()
+    assert L.mi355_rank_workspace_bytes(256, 100000, 1536, 3) > 256 * 100000 * 4
+    assert L.mi355_rank_workspace_bytes(0, 10, 8, 1) == 0

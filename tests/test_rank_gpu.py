@@ -1,0 +1,184 @@
+"""Parity of the HIP rank path (through the C ABI) against the oracle and the reference-generated goldens."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import SCORE_TOL, assert_topk_matches, load_golden
+import imageretrievalresearch_amd as M
+from imageretrievalresearch_amd import synth
+from oracle import rank as orank
+
+pytestmark = pytest.mark.gpu
+GOLD = load_golden()
+DEV = "cuda:0"
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def test_native_library_is_loaded():
+    assert M.lib().mi355_device_count() >= 1
+
+
+@pytest.mark.parametrize("kind", [synth.UNIFORM, synth.NORMAL])
+def test_synth_fill_bit_identical_to_numpy(kind):
+    n, seed, off = 100003, 77, 12345
+    got = M.synth_fill(n, seed, kind, DEV, offset=off).cpu().numpy()
+    np.testing.assert_array_equal(got, synth.fill(seed, n, kind, offset=off))
+
+
+@pytest.mark.parametrize("case", ["cfg1", "cfg2", "g100k"])
+def test_cosine_topk_matches_reference_goldens(case):
+    qs, Qn, gs, Gn, d = (int(x) for x in GOLD[f"{case}_meta"])
+    Q = M.synth_fill(Qn * d, qs, synth.NORMAL, DEV).view(Qn, d)
+    G = M.synth_fill(Gn * d, gs, synth.NORMAL, DEV).view(Gn, d)
+    ks = [k for k in (1, 3, 150) if f"{case}_k{k}_idx" in GOLD.files]
+    for pre in (False, True):
+        gal = M.l2_normalize_rows(G) if pre else G
+        for k in ks:
+            v, i = M.cosine_topk(Q, gal, k, gallery_is_normalized=pre)
+            ncert = assert_topk_matches(v.cpu().numpy(), i.cpu().numpy(), GOLD[f"{case}_k{k}_val"],
+                                        GOLD[f"{case}_k{k}_idx"], GOLD[f"{case}_k{k}_gap"],
+                                        float(GOLD["cert_gap"]), f"{case} k={k} pre={pre}")
+            if k <= 3:
+                assert ncert >= Qn - 2
+
+
+def test_1m_gallery_probe_queries():
+    if "g1m_meta" not in GOLD.files:
+        pytest.skip("1M-row goldens not generated")
+    qs, Qn, gs, Gn, d = (int(x) for x in GOLD["g1m_meta"])
+    Q = M.synth_fill(Qn * d, qs, synth.NORMAL, DEV).view(Qn, d)
+    G = M.synth_fill(Gn * d, gs, synth.NORMAL, DEV).view(Gn, d)
+    v, i = M.cosine_topk(Q, G, 3)
+    assert_topk_matches(v.cpu().numpy(), i.cpu().numpy(), GOLD["g1m_k3_val"], GOLD["g1m_k3_idx"],
+                        GOLD["g1m_k3_gap"], float(GOLD["cert_gap"]), "g1m k=3")
+
+
+@pytest.mark.parametrize("Q,G,D,k", [(1, 1, 4, 1), (1, 7, 5, 3), (3, 129, 33, 8), (65, 300, 100, 5),
+                                      (130, 2049, 64, 9), (257, 1000, 1000, 150), (16, 5000, 1920, 1024),
+                                      (2, 20000, 17, 4)])
+def test_ragged_shapes_against_oracle(Q, G, D, k):
+    q, g = synth.normal(100 + Q, (Q, D)), synth.normal(200 + G, (G, D))
+    want_v, want_i = orank.rank_topk(q, g, k)
+    S = orank.cosine_scores(q, g)
+    gaps = np.array([orank.kth_gap(S[r:r + 1], min(k, G - 1)) if G > 1 else 1.0 for r in range(Q)])
+    v, i = M.cosine_topk(dev(q), dev(g), k)
+    assert_topk_matches(v.cpu().numpy(), i.cpu().numpy(), want_v, want_i, gaps, 1e-5, f"Q{Q} G{G} D{D} k{k}")
+    s = M.cosine_scores(dev(q), dev(g)).cpu().numpy()
+    np.testing.assert_allclose(s, S, atol=SCORE_TOL)
+
+
+def test_ties_resolve_to_lower_index():
+    S = np.zeros((3, 5000), np.float32)
+    S[0, [10, 4000, 77]] = 1.0          # three-way tie at the top
+    S[1, :] = 0.25                      # everything tied
+    S[2, 4999] = 2.0
+    for k in (1, 3, 8, 40):
+        v, i = M.topk(dev(S), k)
+        wv, wi = orank.topk_rows(S, k)
+        np.testing.assert_array_equal(i.cpu().numpy(), wi)
+        np.testing.assert_array_equal(v.cpu().numpy(), wv)
+    # duplicate gallery rows tie exactly in the fused path as well
+    g = synth.normal(5, (300, 64))
+    g[250] = g[3]
+    g[17] = g[3]
+    v, i = M.cosine_topk(dev(g[3:4]), dev(g), 3)
+    assert i.cpu().numpy().tolist() == [[3, 17, 250]]
+
+
+def test_topk_1d_like_torch_and_errors():
+    s = synth.normal(9, (1000,))
+    v, i = M.topk(dev(s), 3)
+    tv, ti = torch.topk(torch.from_numpy(s), 3)
+    assert i.cpu().tolist() == ti.tolist() and torch.equal(v.cpu(), tv)
+    with pytest.raises(M.MI355Error):
+        M.topk(dev(s), 1001)
+    with pytest.raises(M.MI355Error):
+        M.cosine_topk(dev(synth.normal(1, (2, 8))), dev(synth.normal(2, (3, 8))), 4)
+    with pytest.raises(M.MI355Error):
+        M.cosine_topk(dev(synth.normal(1, (2, 8))), dev(synth.normal(2, (3, 9))), 1)
+    with pytest.raises(M.MI355Error):
+        M.cosine_topk(torch.zeros(2, 8), torch.zeros(3, 8), 1)   # CPU tensors: no fallback
+
+
+def test_merge_topk_equals_unsharded():
+    q, g = synth.normal(31, (37, 256)), synth.normal(32, (4000, 256))
+    k = 5
+    full_v, full_i = M.cosine_topk(dev(q), dev(g), k)
+    cv, ci = [], []
+    bounds = [0, 1000, 1001, 2500, 4000]       # ragged shards, one of a single row... (k > rows handled below)
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        kk = min(k, b - a)
+        v, i = M.cosine_topk(dev(q), dev(g[a:b]), kk, idx_offset=a)
+        if kk < k:  # pad short shards the way ShardedGallery does
+            v = torch.cat([v, torch.full((37, k - kk), -float("inf"), device=DEV)], 1)
+            i = torch.cat([i, torch.full((37, k - kk), 2 ** 62, dtype=torch.int64, device=DEV)], 1)
+        cv.append(v)
+        ci.append(i)
+    mv, mi = M.merge_topk(torch.cat(cv, 1), torch.cat(ci, 1), k)
+    assert torch.equal(mi, full_i) and torch.equal(mv, full_v)
+
+
+def test_pair_cosine_and_module_shapes():
+    for case in ("cfg1", "cfg2"):
+        qs, Qn, gs, Gn, d = (int(x) for x in GOLD[f"{case}_meta"])
+        Q, G = synth.normal(qs, (Qn, d)), synth.normal(gs, (Qn, d))
+        got = M.pair_cosine(dev(Q), dev(G)).cpu().numpy()
+        np.testing.assert_allclose(got, GOLD[f"{case}_pair"], atol=SCORE_TOL)
+    cos = M.CosineSimilarity(dim=1, eps=1e-6)
+    a, b = synth.normal(1, (6, 40)), synth.normal(2, (50, 40))
+    one_vs_many = cos(dev(a[:1]), dev(b)).cpu().numpy()          # train/train.py:250 shape
+    np.testing.assert_allclose(one_vs_many, orank.cosine_scores(a[:1], b)[0], atol=SCORE_TOL)
+    z = np.zeros((2, 40), np.float32)                            # zero rows: eps clamp, no NaN
+    assert torch.isfinite(cos(dev(z), dev(a[:2]))).all()
+
+
+def test_contrastive_loss_matches_reference_goldens():
+    s1, s2, n, d = (int(x) for x in GOLD["cl_seeds"])
+    a = dev(synth.normal(s1, (n, d)) * np.float32(GOLD["cl_scale"]))
+    b = dev(synth.normal(s2, (n, d)) * np.float32(GOLD["cl_scale"]))
+    for margin, label, mean, want in GOLD["cl_cases"]:
+        got = M.ContrastiveLoss(margin)(a, b, label, bool(mean)).item()
+        assert got == pytest.approx(want, rel=1e-5), (margin, label, mean)
+    s1, s2, n, d = (int(x) for x in GOLD["cl_infer_seeds"])
+    a, b = dev(synth.normal(s1, (n, d))), dev(synth.normal(s2, (n, d)))
+    assert M.ContrastiveLoss(0.5)(a, b, 1.).item() == pytest.approx(GOLD["cl_infer"][0], rel=1e-5)
+    assert M.ContrastiveLoss(0.5)(a, b, 0., False).item() == pytest.approx(GOLD["cl_infer"][1], rel=1e-5, abs=1e-7)
+
+
+def test_hit_counts_and_distinct_classes_match_oracle():
+    q, g = synth.normal(41, (200, 128)), synth.normal(42, (3000, 128))
+    gcls = (np.arange(3000) * 7919 % 25).astype(np.int64)
+    qcls = (np.arange(200) * 31 % 25).astype(np.int64)
+    v, i = M.cosine_topk(dev(q), dev(g), 150)
+    want = orank.hit_counts(i.cpu().numpy(), qcls, gcls)
+    got = M.hit_counts(i, dev(qcls), dev(gcls)).cpu().tolist()
+    assert tuple(got) == want
+    oc, oi, ov = M.distinct_class_topn(i, v, dev(gcls), 3)
+    wc, wi, wv = orank.distinct_class_top3(i.cpu().numpy(), v.cpu().numpy(), gcls)
+    np.testing.assert_array_equal(oc.cpu().numpy(), wc)
+    np.testing.assert_array_equal(oi.cpu().numpy(), wi)
+    np.testing.assert_array_equal(ov.cpu().numpy(), wv)
+
+
+def test_rank_is_deterministic_run_to_run():
+    Q = M.synth_fill(256 * 1536, 1, synth.NORMAL, DEV).view(256, 1536)
+    G = M.synth_fill(20000 * 1536, 2, synth.NORMAL, DEV).view(20000, 1536)
+    v1, i1 = M.cosine_topk(Q, G, 3)
+    v2, i2 = M.cosine_topk(Q, G, 3)
+    assert torch.equal(v1, v2) and torch.equal(i1, i2)
+
+
+def test_gallery_object_and_metrics():
+    emb = synth.normal(51, (500, 96))
+    cls = (np.arange(500) % 10).astype(np.int64)
+    gal = M.Gallery(96, DEV)
+    gal.add(dev(emb[:200]), dev(cls[:200])).add(dev(emb[200:]), dev(cls[200:]))
+    assert len(gal) == 500
+    v, i = gal.search(dev(emb[:64]), 3)
+    assert (i[:, 0].cpu().numpy() == np.arange(64)).all()           # each row finds itself first
+    np.testing.assert_allclose(v[:, 0].cpu().numpy(), 1.0, atol=SCORE_TOL)
+    m = M.retrieval_metrics(dev(emb[:64]), dev(emb[:64]), dev(cls[:64]))
+    assert m["top1"] == 1.0 and m["top3"] == 1.0 and abs(m["scores"] - 1.0) < SCORE_TOL
