@@ -8,6 +8,7 @@ for device memory, streams and torch.distributed only.
 """
 from . import synth  # noqa: F401
 from ._lib import MI355Error, lib, LIB_PATH  # noqa: F401
+from . import models  # noqa: F401
 from .rank import (ContrastiveLoss, CosineSimilarity, Gallery, cosine_scores, cosine_topk,  # noqa: F401
                    distinct_class_topn, hit_counts, l2_normalize_rows, merge_topk, pair_cosine,
                    retrieval_metrics, synth_fill, topk)

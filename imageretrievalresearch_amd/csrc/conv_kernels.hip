@@ -1,0 +1,364 @@
+// Non-GEMM kernels of the conv backbones: stem 3x3/s2, depthwise kxk (+ SE squeeze partial sums),
+// SE gate, global average pool, layout conversion, conv_input pre-stem.  gfx950 only.
+// Activations are NHWC bf16 (channels multiple of 8 -> every access is a 16-byte vector of 8 channels);
+// all arithmetic is fp32 on the VALU: these layers are byte-bound, not FLOP-bound.
+#include "ops.h"
+
+namespace mi355 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void unpack8(u32x4 v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+    u32x4 o;
+    o.x = pack2bf(f[0], f[1]); o.y = pack2bf(f[2], f[3]); o.z = pack2bf(f[4], f[5]); o.w = pack2bf(f[6], f[7]);
+    return o;
+}
+
+// =====================================================================================
+// stem: 3x3 stride 2 pad 1, 3 -> Cout, NCHW fp32 in, NHWC bf16 out.  One thread = one output pixel,
+// the 27-tap patch lives in registers, weights [27][Cout] are broadcast-read from LDS.
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const float* __restrict__ w,
+                                              const float* __restrict__ bias, bf16_t* __restrict__ out, int H, int W,
+                                              int Ho, int Wo, int Cout, int act) {
+    extern __shared__ __attribute__((aligned(16))) float sw[];  // [27][Cout] then bias [Cout]
+    float* sb = sw + 27 * Cout;
+    for (int i = threadIdx.x; i < 27 * Cout; i += 256) sw[i] = w[i];
+    for (int i = threadIdx.x; i < Cout; i += 256) sb[i] = bias[i];
+    __syncthreads();
+    const int b = blockIdx.z;
+    const int ox = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int oy = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (ox >= Wo || oy >= Ho) return;
+    float p[27];
+    const float* xb = x + (size_t)b * 3 * H * W;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 - 1 + ky;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * 2 - 1 + kx;
+            const bool ok = (iy >= 0 && iy < H && ix >= 0 && ix < W);
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci)
+                p[(ky * 3 + kx) * 3 + ci] = ok ? xb[((size_t)ci * H + iy) * W + ix] : 0.f;
+        }
+    }
+    bf16_t* o = out + (((size_t)b * Ho + oy) * Wo + ox) * Cout;
+    for (int c0 = 0; c0 < Cout; c0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = sb[c0 + j];
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(&sw[t * Cout + c0]);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(&sw[t * Cout + c0 + 4]);
+            acc[0] += p[t] * w0.x; acc[1] += p[t] * w0.y; acc[2] += p[t] * w0.z; acc[3] += p[t] * w0.w;
+            acc[4] += p[t] * w1.x; acc[5] += p[t] * w1.y; acc[6] += p[t] * w1.z; acc[7] += p[t] * w1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = apply_act(acc[j], act);
+        *reinterpret_cast<u32x4*>(o + c0) = pack8(acc);
+    }
+}
+
+int launch_stem(const float* x, const float* w, const float* bias, bf16_t* out, int B, int H, int W, int Cout, int act,
+                hipStream_t st) {
+    MI355_REQUIRE(Cout % 8 == 0 && Cout <= 256, "stem: Cout=%d must be a multiple of 8 and <= 256", Cout);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    dim3 grid(cdiv(Wo, 32), cdiv(Ho, 8), B);
+    hipLaunchKernelGGL(k_stem, grid, dim3(256), (27 + 1) * Cout * sizeof(float), st, x, w, bias, out, H, W, Ho, Wo,
+                       Cout, act);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
+// =====================================================================================
+// depthwise k x k.  One thread = 8 channels x PX consecutive output pixels of one row.
+// Threads are laid out channel-group fastest, so a wave reads/writes contiguous NHWC bytes.
+// SE squeeze: each thread sums its (un-rounded, activated) outputs; threads of a block that share a
+// channel group are combined through LDS in thread order -> pool_partial[b][blk][C], deterministic.
+// =====================================================================================
+constexpr int DW_PX = 4;
+
+int dw_pool_blocks(int Ho, int Wo, int C) {
+    const long items = (long)(C / 8) * cdiv(Wo, DW_PX) * Ho;
+    return cdiv(items, 256);
+}
+
+template <int KS, int S>
+__global__ __launch_bounds__(256) void k_dwconv(const bf16_t* __restrict__ in, const bf16_t* __restrict__ w,
+                                                const float* __restrict__ bias, bf16_t* __restrict__ out,
+                                                float* __restrict__ pool_partial, int H, int W, int C, int Ho, int Wo,
+                                                int act) {
+    constexpr int PAD = KS / 2;
+    constexpr int IW = (DW_PX - 1) * S + KS;  // input columns touched by one thread
+    __shared__ float red[256][8];
+    const int CG = C >> 3;
+    const int strips = (Wo + DW_PX - 1) / DW_PX;
+    const int b = blockIdx.y;
+    const long item = (long)blockIdx.x * 256 + threadIdx.x;
+    const long nitems = (long)CG * strips * Ho;
+    const bool live = item < nitems;
+    const int cg = (int)(item % CG);
+    const long rest = item / CG;
+    const int sx = (int)(rest % strips);
+    const int oy = (int)(rest / strips);
+    const int ox0 = sx * DW_PX;
+    const int c0 = cg * 8;
+
+    float acc[DW_PX][8];
+    float psum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) psum[j] = 0.f;
+
+    if (live) {
+        float bs[8];
+        {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + c0);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + c0 + 4);
+            bs[0] = b0.x; bs[1] = b0.y; bs[2] = b0.z; bs[3] = b0.w; bs[4] = b1.x; bs[5] = b1.y; bs[6] = b1.z; bs[7] = b1.w;
+        }
+#pragma unroll
+        for (int p = 0; p < DW_PX; ++p)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[p][j] = bs[j];
+
+        const bf16_t* inb = in + (size_t)b * H * W * C + c0;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            const int iy = oy * S - PAD + ky;
+            if (iy < 0 || iy >= H) continue;
+            float wk[KS][8];
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx)
+                unpack8(*reinterpret_cast<const u32x4*>(w + (size_t)(ky * KS + kx) * C + c0), wk[kx]);
+            const bf16_t* row = inb + (size_t)iy * W * C;
+#pragma unroll
+            for (int i = 0; i < IW; ++i) {
+                const int ix = ox0 * S - PAD + i;
+                if (ix < 0 || ix >= W) continue;
+                float v[8];
+                unpack8(*reinterpret_cast<const u32x4*>(row + (size_t)ix * C), v);
+#pragma unroll
+                for (int p = 0; p < DW_PX; ++p) {
+                    const int kx = i - p * S;  // compile-time after unrolling
+                    if (kx >= 0 && kx < KS) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[p][j] += wk[kx][j] * v[j];
+                    }
+                }
+            }
+        }
+        bf16_t* o = out + (((size_t)b * Ho + oy) * Wo + ox0) * C + c0;
+#pragma unroll
+        for (int p = 0; p < DW_PX; ++p) {
+            if (ox0 + p < Wo) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc[p][j] = apply_act(acc[p][j], act);
+                    psum[j] += acc[p][j];
+                }
+                *reinterpret_cast<u32x4*>(o + (size_t)p * C) = pack8(acc[p]);
+            }
+        }
+    }
+
+    if (pool_partial != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = psum[j];
+        __syncthreads();
+        // thread t < min(CG,256) owns the channel group (first_cg + t) % CG of this block
+        const int ncg = CG < 256 ? CG : 256;
+        if ((int)threadIdx.x < ncg) {
+            float s[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] = 0.f;
+            for (int u = threadIdx.x; u < 256; u += CG) {   // same cg: every CG-th thread, in thread order
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] += red[u][j];
+            }
+            const int my_cg = (int)(((long)blockIdx.x * 256 + threadIdx.x) % CG);
+            float* pp = pool_partial + ((size_t)b * gridDim.x + blockIdx.x) * C + my_cg * 8;
+            *reinterpret_cast<f32x4*>(pp) = (f32x4){s[0], s[1], s[2], s[3]};
+            *reinterpret_cast<f32x4*>(pp + 4) = (f32x4){s[4], s[5], s[6], s[7]};
+        }
+        // channel groups this block did not touch (CG > 256) must read as zero
+        if (CG > 256) {
+            const int first = (int)(((long)blockIdx.x * 256) % CG);
+            for (int t = 256 + threadIdx.x; t < CG; t += 256) {
+                const int z = (first + t) % CG;
+                float* pp = pool_partial + ((size_t)b * gridDim.x + blockIdx.x) * C + z * 8;
+                *reinterpret_cast<f32x4*>(pp) = (f32x4){0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(pp + 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+}
+
+int launch_dwconv(const bf16_t* in, const bf16_t* w, const float* bias, bf16_t* out, float* pool_partial, int B, int H,
+                  int W, int C, int k, int stride, int act, hipStream_t st) {
+    MI355_REQUIRE(C % 8 == 0, "dwconv: C=%d must be a multiple of 8", C);
+    MI355_REQUIRE((k == 3 || k == 5) && (stride == 1 || stride == 2), "dwconv: unsupported k=%d stride=%d", k, stride);
+    const int pad = k / 2;
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    dim3 grid(dw_pool_blocks(Ho, Wo, C), B);
+#define DW_LAUNCH(KS, S)                                                                                            \
+    hipLaunchKernelGGL((k_dwconv<KS, S>), grid, dim3(256), 0, st, in, w, bias, out, pool_partial, H, W, C, Ho, Wo, act)
+    if (k == 3 && stride == 1) DW_LAUNCH(3, 1);
+    else if (k == 3 && stride == 2) DW_LAUNCH(3, 2);
+    else if (k == 5 && stride == 1) DW_LAUNCH(5, 1);
+    else DW_LAUNCH(5, 2);
+#undef DW_LAUNCH
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
+// =====================================================================================
+// SE gate.  One block per image.
+// =====================================================================================
+constexpr int SE_MAX_C = 4096;
+constexpr int SE_MAX_RD = 512;
+__global__ __launch_bounds__(256) void k_se(const float* __restrict__ pool_partial, int nblk, float inv_hw,
+                                            const float* __restrict__ w1, const float* __restrict__ b1,
+                                            const float* __restrict__ w2, const float* __restrict__ b2,
+                                            float* __restrict__ gate, int C, int rd, int act1) {
+    __shared__ float s[SE_MAX_C];
+    __shared__ float r[SE_MAX_RD];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* pp = pool_partial + (size_t)b * nblk * C;
+    for (int c = tid; c < C; c += 256) {
+        float a = 0.f;
+        for (int k = 0; k < nblk; ++k) a += pp[(size_t)k * C + c];   // fixed order
+        s[c] = a * inv_hw;
+    }
+    __syncthreads();
+    for (int j = wave; j < rd; j += 4) {
+        const float* wr = w1 + (size_t)j * C;
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a += wr[c] * s[c];
+        a = wave_sum(a);
+        if (lane == 0) r[j] = apply_act(a + b1[j], act1);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const float* wr = w2 + (size_t)c * rd;
+        float a = b2[c];
+        for (int j = 0; j < rd; ++j) a += wr[j] * r[j];
+        gate[(size_t)b * C + c] = sigmoid_f(a);
+    }
+}
+
+int launch_se(const float* pool_partial, int nblk, float inv_hw, const float* w1, const float* b1, const float* w2,
+              const float* b2, float* gate, int B, int C, int rd, int act1, hipStream_t st) {
+    MI355_REQUIRE(C <= SE_MAX_C && rd <= SE_MAX_RD, "se: C=%d rd=%d exceed limits", C, rd);
+    hipLaunchKernelGGL(k_se, dim3(B), dim3(256), 0, st, pool_partial, nblk, inv_hw, w1, b1, w2, b2, gate, C, rd, act1);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
+// =====================================================================================
+// global average pool, layout conversion, conv_input
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_gap(const bf16_t* __restrict__ in, float* __restrict__ pooled,
+                                             bf16_t* __restrict__ pooled_bf16, int HW, int C, long total) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int CG = C >> 3;
+    const int cg = (int)(t % CG);
+    const long b = t / CG;
+    const bf16_t* p = in + (size_t)b * HW * C + cg * 8;
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < HW; ++i) {
+        float v[8];
+        unpack8(*reinterpret_cast<const u32x4*>(p + (size_t)i * C), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += v[j];
+    }
+    const float inv = 1.0f / (float)HW;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] *= inv;
+    float* o = pooled + (size_t)b * C + cg * 8;
+    *reinterpret_cast<f32x4*>(o) = (f32x4){a[0], a[1], a[2], a[3]};
+    *reinterpret_cast<f32x4*>(o + 4) = (f32x4){a[4], a[5], a[6], a[7]};
+    if (pooled_bf16) *reinterpret_cast<u32x4*>(pooled_bf16 + (size_t)b * C + cg * 8) = pack8(a);
+}
+
+int launch_gap(const bf16_t* in, float* pooled, bf16_t* pooled_bf16, int B, int HW, int C, hipStream_t st) {
+    MI355_REQUIRE(C % 8 == 0, "gap: C=%d must be a multiple of 8", C);
+    const long total = (long)B * (C / 8);
+    hipLaunchKernelGGL(k_gap, dim3(cdiv(total, 256)), dim3(256), 0, st, in, pooled, pooled_bf16, HW, C, total);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
+// out[b][c][p] = in[b][p][c]; 32x32 tile transpose through LDS so both sides are coalesced.
+__global__ __launch_bounds__(256) void k_nhwc_to_nchw(const bf16_t* __restrict__ in, float* __restrict__ out, int HW,
+                                                      int C, int Cvalid) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int p = p0 + i, c = c0 + tx;
+        tile[i][tx] = (p < HW && c < C) ? bf2f(in[((size_t)b * HW + p) * C + c]) : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, p = p0 + tx;
+        if (c < Cvalid && p < HW) out[((size_t)b * Cvalid + c) * HW + p] = tile[tx][i];
+    }
+}
+
+int launch_nhwc_to_nchw_f32(const bf16_t* in, float* out, int B, int HW, int C, int Cvalid, hipStream_t st) {
+    dim3 grid(cdiv(HW, 32), cdiv(C, 32), B);
+    hipLaunchKernelGGL(k_nhwc_to_nchw, grid, dim3(256), 0, st, in, out, HW, C, Cvalid);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
+__global__ __launch_bounds__(256) void k_conv_input_silu(const float* __restrict__ x, const float* __restrict__ w,
+                                                         float* __restrict__ out, int H, int W) {
+    __shared__ float sw[81];
+    if (threadIdx.x < 81) sw[threadIdx.x] = w[threadIdx.x];
+    __syncthreads();
+    const int b = blockIdx.z;
+    const int ox = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int oy = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (ox >= W || oy >= H) return;
+    const float* xb = x + (size_t)b * 3 * H * W;
+    float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy - 1 + ky;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox - 1 + kx;
+                const float v = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? xb[((size_t)ci * H + iy) * W + ix] : 0.f;
+#pragma unroll
+                for (int co = 0; co < 3; ++co) acc[co] += v * sw[((co * 3 + ci) * 3 + ky) * 3 + kx];
+            }
+        }
+    float* ob = out + (size_t)b * 3 * H * W;
+#pragma unroll
+    for (int co = 0; co < 3; ++co) ob[((size_t)co * H + oy) * W + ox] = silu_f(acc[co]);
+}
+
+int launch_conv_input_silu(const float* x, const float* w, int B, int H, int W, float* out, hipStream_t st) {
+    dim3 grid(cdiv(W, 32), cdiv(H, 8), B);
+    hipLaunchKernelGGL(k_conv_input_silu, grid, dim3(256), 0, st, x, w, out, H, W);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
+}  // namespace mi355

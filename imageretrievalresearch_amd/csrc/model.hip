@@ -1,0 +1,676 @@
+// Model object behind the C ABI: tensor table, one-time weight pack (BN fold -> bf16 -> kernel layout),
+// arena, and the executor that walks the op plan launching the HIP kernels on the caller's stream.
+// Replaces timm.create_model(...) + .forward/.forward_features (see include/mi355_retrieval.h).
+#include "model.h"
+#include "../../include/mi355_retrieval.h"
+
+#include <string.h>
+
+#include <algorithm>
+
+namespace mi355 {
+
+// implemented in swin_kernels.hip
+int swin_exec(const ModelDef& def, const Op& op, struct ExecCtx& cx);
+
+static inline uint16_t f2bf_host(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf_round_host(float f) {
+    uint32_t u = ((uint32_t)f2bf_host(f)) << 16;
+    float r;
+    memcpy(&r, &u, 4);
+    return r;
+}
+
+struct SlotState {
+    size_t off = 0, bytes = 0;
+    int h = 0, w = 0, c = 0;
+};
+
+struct TapBuf {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    int B = 0, h = 0, w = 0, c = 0, c_real = 0;
+};
+
+enum { PK_STEM = 0, PK_GEMM, PK_DW, PK_SE, PK_OTHER, PK_ATTN, PK_LN, PK_COUNT };
+
+}  // namespace mi355
+
+using namespace mi355;
+
+struct mi355_model {
+    ModelDef def;
+    std::vector<char> blob;
+    void* dev_blob = nullptr;
+    size_t dev_blob_bytes = 0;
+    bool packed = false;
+    void* arena = nullptr;
+    size_t arena_bytes = 0;
+    SlotState slots[SLOT_COUNT];
+    int microbatch = 0;
+    bool taps = false;
+    std::map<std::string, TapBuf> tapbufs;
+    // per-kind profiling with hipEvents (option "profile")
+    bool profile = false;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
+    double prof_ms[PK_COUNT] = {0};
+    long prof_launches[PK_COUNT] = {0};
+};
+
+namespace mi355 {
+
+struct ExecCtx {
+    mi355_model* m;
+    hipStream_t st;
+    int nb, H, W;          // chunk batch, input size
+    const float* x;        // chunk input (NCHW fp32)
+    int b0, B;             // chunk offset / full batch (for taps)
+    char* base() const { return (char*)m->arena; }
+    void* slot_ptr(int s) const { return s == SLOT_NONE ? nullptr : base() + m->slots[s].off; }
+    const char* w(size_t off) const { return (const char*)m->dev_blob + off; }
+};
+
+// ------------------------------------------------------------------------------------ packing
+struct Packer {
+    mi355_model* m;
+    std::vector<char>& blob;
+    size_t alloc(size_t bytes) {
+        const size_t off = align_up(blob.size(), 256);
+        blob.resize(off + bytes, 0);
+        return off;
+    }
+    const TensorSpec* get(const std::string& name) {
+        auto it = m->def.index.find(name);
+        if (it == m->def.index.end()) { set_error("pack: unknown tensor '%s'", name.c_str()); return nullptr; }
+        const TensorSpec& t = m->def.tensors[it->second];
+        if (!t.set) { set_error("pack: tensor '%s' was never set (mi355_model_set_tensor)", name.c_str()); return nullptr; }
+        return &t;
+    }
+    // per-output-channel (scale, shift) of an eval-mode BN, in the same fp32 op order as the oracle
+    bool bn_fold(const std::string& bn, float eps, int n, std::vector<float>& scale, std::vector<float>& shift) {
+        scale.assign(n, 1.f);
+        shift.assign(n, 0.f);
+        if (bn.empty()) return true;
+        const TensorSpec *g = get(bn + ".weight"), *b = get(bn + ".bias"), *mu = get(bn + ".running_mean"),
+                         *var = get(bn + ".running_var");
+        if (!g || !b || !mu || !var) return false;
+        for (int i = 0; i < n; ++i) {
+            const float s = g->data[i] / sqrtf(var->data[i] + eps);
+            scale[i] = s;
+            shift[i] = b->data[i] - mu->data[i] * s;
+        }
+        return true;
+    }
+};
+
+static int pack_gemm(Packer& pk, Op& op) {
+    const TensorSpec* w = pk.get(op.w_name);
+    if (!w) return ERR_STATE;
+    const int N = op.cout_real, K = op.cin_real;
+    MI355_REQUIRE(w->numel() == (int64_t)N * K, "pack: %s has %lld elements, expected %d x %d", op.w_name.c_str(),
+                  (long long)w->numel(), N, K);
+    std::vector<float> scale, shift;
+    if (!pk.bn_fold(op.bn_name, op.bn_eps, N, scale, shift)) return ERR_STATE;
+    if (!op.bias_name.empty()) {
+        const TensorSpec* b = pk.get(op.bias_name);
+        if (!b) return ERR_STATE;
+        for (int i = 0; i < N; ++i) shift[i] = b->data[i] * scale[i] + shift[i];
+    }
+    const int Np = (op.cout + 15) & ~15, Kp = (op.cin + 31) & ~31;
+    op.w_off = pk.alloc((size_t)Np * Kp * 2);
+    op.b_off = pk.alloc((size_t)Np * 4);
+    uint16_t* W = (uint16_t*)(pk.blob.data() + op.w_off);
+    float* Bv = (float*)(pk.blob.data() + op.b_off);
+    for (int n = 0; n < N; ++n) {
+        for (int k = 0; k < K; ++k) W[(size_t)n * Kp + k] = f2bf_host(w->data[(size_t)n * K + k] * scale[n]);
+        Bv[n] = shift[n];
+    }
+    return OK;
+}
+
+static int pack_dw(Packer& pk, Op& op) {
+    const TensorSpec* w = pk.get(op.w_name);
+    if (!w) return ERR_STATE;
+    const int C = op.cin_real, Cp = op.cin, kk = op.k * op.k;
+    MI355_REQUIRE(w->numel() == (int64_t)C * kk, "pack: %s has %lld elements, expected %d x %d", op.w_name.c_str(),
+                  (long long)w->numel(), C, kk);
+    std::vector<float> scale, shift;
+    if (!pk.bn_fold(op.bn_name, op.bn_eps, C, scale, shift)) return ERR_STATE;
+    op.w_off = pk.alloc((size_t)kk * Cp * 2);
+    op.b_off = pk.alloc((size_t)Cp * 4);
+    uint16_t* W = (uint16_t*)(pk.blob.data() + op.w_off);
+    float* Bv = (float*)(pk.blob.data() + op.b_off);
+    for (int c = 0; c < C; ++c) {
+        for (int t = 0; t < kk; ++t) W[(size_t)t * Cp + c] = f2bf_host(w->data[(size_t)c * kk + t] * scale[c]);
+        Bv[c] = shift[c];
+    }
+    return OK;
+}
+
+static int pack_stem(Packer& pk, Op& op) {
+    const TensorSpec* w = pk.get(op.w_name);
+    if (!w) return ERR_STATE;
+    const int Co = op.cout_real, Cp = op.cout;
+    MI355_REQUIRE(w->numel() == (int64_t)Co * 27, "pack: %s has %lld elements, expected %d x 27", op.w_name.c_str(),
+                  (long long)w->numel(), Co);
+    std::vector<float> scale, shift;
+    if (!pk.bn_fold(op.bn_name, op.bn_eps, Co, scale, shift)) return ERR_STATE;
+    op.w_off = pk.alloc((size_t)27 * Cp * 4);
+    op.b_off = pk.alloc((size_t)Cp * 4);
+    float* W = (float*)(pk.blob.data() + op.w_off);
+    float* Bv = (float*)(pk.blob.data() + op.b_off);
+    for (int co = 0; co < Co; ++co) {
+        for (int ci = 0; ci < 3; ++ci)
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx)
+                    W[(size_t)((ky * 3 + kx) * 3 + ci) * Cp + co] =
+                        bf_round_host(w->data[(((size_t)co * 3 + ci) * 3 + ky) * 3 + kx] * scale[co]);
+        Bv[co] = shift[co];
+    }
+    return OK;
+}
+
+static int pack_se(Packer& pk, Op& op) {
+    const TensorSpec *w1 = pk.get(op.w_name), *b1 = pk.get(op.bias_name), *w2 = pk.get(op.w2_name),
+                     *b2 = pk.get(op.bias2_name);
+    if (!w1 || !b1 || !w2 || !b2) return ERR_STATE;
+    const int C = op.cin_real, Cp = op.cin, rd = op.rd;
+    MI355_REQUIRE(w1->numel() == (int64_t)rd * C && w2->numel() == (int64_t)C * rd, "pack: SE %s shape mismatch",
+                  op.w_name.c_str());
+    std::vector<float> scale, shift;  // rexnet: BN between the reduce FC and its ReLU
+    if (!pk.bn_fold(op.bn2_name, op.bn_eps, rd, scale, shift)) return ERR_STATE;
+    op.w_off = pk.alloc((size_t)rd * Cp * 4);
+    op.b_off = pk.alloc((size_t)rd * 4);
+    op.w2_off = pk.alloc((size_t)Cp * rd * 4);
+    op.b2_off = pk.alloc((size_t)Cp * 4);
+    float* W1 = (float*)(pk.blob.data() + op.w_off);
+    float* B1 = (float*)(pk.blob.data() + op.b_off);
+    float* W2 = (float*)(pk.blob.data() + op.w2_off);
+    float* B2 = (float*)(pk.blob.data() + op.b2_off);
+    for (int j = 0; j < rd; ++j) {
+        for (int c = 0; c < C; ++c) W1[(size_t)j * Cp + c] = w1->data[(size_t)j * C + c] * scale[j];
+        B1[j] = b1->data[j] * scale[j] + shift[j];
+    }
+    for (int c = 0; c < C; ++c) {
+        for (int j = 0; j < rd; ++j) W2[(size_t)c * rd + j] = w2->data[(size_t)c * rd + j];
+        B2[c] = b2->data[c];
+    }
+    return OK;
+}
+
+int swin_pack(Packer& pk, Op& op);  // swin_kernels.hip
+
+static int pack_op(Packer& pk, Op& op) {
+    switch (op.kind) {
+        case OP_STEM: return pack_stem(pk, op);
+        case OP_GEMM: return pack_gemm(pk, op);
+        case OP_DW: return pack_dw(pk, op);
+        case OP_SE: return pack_se(pk, op);
+        default: return swin_pack(pk, op);
+    }
+}
+
+// ------------------------------------------------------------------------------------ shape pass
+static inline int conv_out(int h, int k, int s) { return (h + 2 * (k / 2) - k) / s + 1; }
+
+// Walk the plan for a chunk of nb images: fill slot dims and sizes.  Returns total arena bytes.
+static size_t plan_slots(mi355_model* m, int nb, int H, int W) {
+    SlotState* S = m->slots;
+    for (int i = 0; i < SLOT_COUNT; ++i) S[i] = SlotState();
+    auto need = [&](int s, size_t bytes) { if (s != SLOT_NONE && bytes > S[s].bytes) S[s].bytes = bytes; };
+    for (const Op& op : m->def.ops) {
+        switch (op.kind) {
+            case OP_STEM: {
+                const int ho = conv_out(H, 3, 2), wo = conv_out(W, 3, 2);
+                S[op.out].h = ho; S[op.out].w = wo; S[op.out].c = op.cout;
+                need(op.out, (size_t)nb * ho * wo * op.cout * 2);
+                break;
+            }
+            case OP_GEMM: {
+                const int h = S[op.in].h, w = S[op.in].w;
+                S[op.out].h = h; S[op.out].w = w; S[op.out].c = op.cout;
+                need(op.out, (size_t)nb * h * w * op.cout * 2);
+                break;
+            }
+            case OP_DW: {
+                const int ho = conv_out(S[op.in].h, op.k, op.stride), wo = conv_out(S[op.in].w, op.k, op.stride);
+                S[op.out].h = ho; S[op.out].w = wo; S[op.out].c = op.cout;
+                need(op.out, (size_t)nb * ho * wo * op.cout * 2);
+                if (op.pool) need(SLOT_POOLPART, (size_t)nb * dw_pool_blocks(ho, wo, op.cout) * op.cout * 4);
+                break;
+            }
+            case OP_SE:
+                need(SLOT_GATE, (size_t)nb * op.cin * 4);
+                break;
+            default: {
+                // swin ops: sizes are declared by the builder through cin/cout/tokens_h
+                const int th = op.tokens_h;
+                S[op.out].h = th; S[op.out].w = th; S[op.out].c = op.cout;
+                need(op.out, (size_t)nb * th * th * op.cout * 2);
+                break;
+            }
+        }
+    }
+    need(SLOT_POOLED, (size_t)nb * m->def.feat_dim_pad * 4);
+    need(SLOT_POOLED_BF16, (size_t)nb * m->def.feat_dim_pad * 2);
+    size_t off = 0;
+    for (int i = 0; i < SLOT_COUNT; ++i) {
+        S[i].off = off;
+        off += align_up(S[i].bytes, 256);
+    }
+    return off + 256;
+}
+
+static int ensure_arena(mi355_model* m, size_t bytes) {
+    if (bytes <= m->arena_bytes) return OK;
+    if (m->arena) {
+        MI355_CHECK_HIP(hipDeviceSynchronize());
+        MI355_CHECK_HIP(hipFree(m->arena));
+        m->arena = nullptr;
+        m->arena_bytes = 0;
+    }
+    MI355_CHECK_HIP(hipMalloc(&m->arena, bytes));
+    m->arena_bytes = bytes;
+    return OK;
+}
+
+// ------------------------------------------------------------------------------------ execution
+static int prof_kind(const Op& op) {
+    switch (op.kind) {
+        case OP_STEM: return PK_STEM;
+        case OP_GEMM: return PK_GEMM;
+        case OP_DW: return PK_DW;
+        case OP_SE: return PK_SE;
+        case OP_WINATTN: return PK_ATTN;
+        case OP_LAYERNORM: case OP_PATCH_MERGE_LN: return PK_LN;
+        default: return PK_OTHER;
+    }
+}
+
+static int record_tap(ExecCtx& cx, const Op& op) {
+    mi355_model* m = cx.m;
+    const SlotState& s = m->slots[op.out];
+    TapBuf& t = m->tapbufs[op.tap];
+    const size_t per_img = (size_t)s.h * s.w * s.c * 2;
+    const size_t bytes = per_img * cx.B;
+    if (t.bytes < bytes) {
+        if (t.ptr) MI355_CHECK_HIP(hipFree(t.ptr));
+        MI355_CHECK_HIP(hipMalloc(&t.ptr, bytes));
+        t.bytes = bytes;
+    }
+    t.B = cx.B; t.h = s.h; t.w = s.w; t.c = s.c; t.c_real = op.cout_real ? op.cout_real : s.c;
+    MI355_CHECK_HIP(hipMemcpyAsync((char*)t.ptr + per_img * cx.b0, cx.slot_ptr(op.out), per_img * cx.nb,
+                                   hipMemcpyDeviceToDevice, cx.st));
+    return OK;
+}
+
+static int exec_op(ExecCtx& cx, const Op& op) {
+    mi355_model* m = cx.m;
+    SlotState* S = m->slots;
+    switch (op.kind) {
+        case OP_STEM:
+            return launch_stem(cx.x, (const float*)cx.w(op.w_off), (const float*)cx.w(op.b_off),
+                               (bf16_t*)cx.slot_ptr(op.out), cx.nb, cx.H, cx.W, op.cout, op.act, cx.st);
+        case OP_GEMM: {
+            const int hw = S[op.in].h * S[op.in].w;
+            GemmArgs a{};
+            a.A = (const bf16_t*)cx.slot_ptr(op.in); a.lda = op.cin;
+            a.W = (const bf16_t*)cx.w(op.w_off); a.ldw = (op.cin + 31) & ~31;
+            a.bias = (const float*)cx.w(op.b_off);
+            a.res = op.res != SLOT_NONE ? (const bf16_t*)cx.slot_ptr(op.res) : nullptr;
+            a.ldr = op.res != SLOT_NONE ? S[op.res].c : 0;
+            a.res_n = op.res_channels ? op.res_channels : op.cout;
+            a.gate = op.use_gate ? (const float*)cx.slot_ptr(SLOT_GATE) : nullptr;
+            a.gate_ld = op.cin; a.rows_per_img = hw;
+            a.out = cx.slot_ptr(op.out); a.ldo = op.cout; a.out_f32 = 0;
+            a.M = cx.nb * hw; a.N = op.cout; a.K = op.cin;
+            a.act = op.act; a.a_relu6 = op.a_relu6;
+            return launch_gemm_bf16(a, cx.st);
+        }
+        case OP_DW:
+            return launch_dwconv((const bf16_t*)cx.slot_ptr(op.in), (const bf16_t*)cx.w(op.w_off),
+                                 (const float*)cx.w(op.b_off), (bf16_t*)cx.slot_ptr(op.out),
+                                 op.pool ? (float*)cx.slot_ptr(SLOT_POOLPART) : nullptr, cx.nb, S[op.in].h, S[op.in].w,
+                                 op.cin, op.k, op.stride, op.act, cx.st);
+        case OP_SE: {
+            // the squeeze partials were produced by the preceding depthwise conv into SLOT_D's geometry
+            const int ho = S[SLOT_D].h, wo = S[SLOT_D].w;
+            return launch_se((const float*)cx.slot_ptr(SLOT_POOLPART), dw_pool_blocks(ho, wo, op.cin),
+                             1.0f / (float)(ho * wo), (const float*)cx.w(op.w_off), (const float*)cx.w(op.b_off),
+                             (const float*)cx.w(op.w2_off), (const float*)cx.w(op.b2_off),
+                             (float*)cx.slot_ptr(SLOT_GATE), cx.nb, op.cin, op.rd, op.se_act, cx.st);
+        }
+        default:
+            return swin_exec(m->def, op, cx);
+    }
+}
+
+static int run_backbone(ExecCtx& cx) {
+    mi355_model* m = cx.m;
+    // NOTE: slot dims for DW/SE depend on walk order; plan_slots() left the LAST writer's dims in each
+    // slot, so re-derive dims incrementally while executing.
+    SlotState* S = m->slots;
+    for (const Op& op : m->def.ops) {
+        switch (op.kind) {
+            case OP_STEM: S[op.out].h = conv_out(cx.H, 3, 2); S[op.out].w = conv_out(cx.W, 3, 2); S[op.out].c = op.cout; break;
+            case OP_GEMM: S[op.out].h = S[op.in].h; S[op.out].w = S[op.in].w; S[op.out].c = op.cout; break;
+            case OP_DW: {
+                const int ho = conv_out(S[op.in].h, op.k, op.stride), wo = conv_out(S[op.in].w, op.k, op.stride);
+                S[op.out].h = ho; S[op.out].w = wo; S[op.out].c = op.cout;
+                break;
+            }
+            case OP_SE: break;
+            default: S[op.out].h = op.tokens_h; S[op.out].w = op.tokens_h; S[op.out].c = op.cout; break;
+        }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (m->profile) {
+            MI355_CHECK_HIP(hipEventCreate(&e0));
+            MI355_CHECK_HIP(hipEventCreate(&e1));
+            MI355_CHECK_HIP(hipEventRecord(e0, cx.st));
+        }
+        if (int e = exec_op(cx, op)) return e;
+        if (m->profile) {
+            MI355_CHECK_HIP(hipEventRecord(e1, cx.st));
+            m->prof_events.push_back({prof_kind(op), {e0, e1}});
+        }
+        if (m->taps && !op.tap.empty())
+            if (int e = record_tap(cx, op)) return e;
+    }
+    return OK;
+}
+
+static int forward_impl(mi355_model* m, const float* x, int B, int H, int W, float* out, float* pooled_out,
+                        bool features_only, hipStream_t st) {
+    MI355_REQUIRE(m, "forward: null model");
+    MI355_REQUIRE(m->packed, "forward: weights not packed (call mi355_model_pack after set_tensor)");
+    MI355_REQUIRE(x && out, "forward: null input/output pointer");
+    MI355_REQUIRE(B >= 1 && H >= 32 && W >= 32, "forward: bad shape B=%d H=%d W=%d", B, H, W);
+    const ModelDef& d = m->def;
+    if (d.pools_in_features) MI355_REQUIRE(H == 224 && W == 224, "forward: %s needs 224x224 input", d.arch.c_str());
+    const int mb = (m->microbatch > 0 && m->microbatch < B) ? m->microbatch : B;
+    const size_t bytes = plan_slots(m, mb, H, W);
+    if (int e = ensure_arena(m, bytes)) return e;
+    const int D = d.feat_dim, Dp = d.feat_dim_pad;
+    for (int b0 = 0; b0 < B; b0 += mb) {
+        const int nb = std::min(mb, B - b0);
+        ExecCtx cx{m, st, nb, H, W, x + (size_t)b0 * 3 * H * W, b0, B};
+        if (int e = run_backbone(cx)) return e;
+        const SlotState& F = m->slots[d.final_slot];
+        const int hw = F.h * F.w;
+        const bool want_logits = !features_only && d.num_classes > 0;
+        if (d.pools_in_features) {
+            // swin: final op wrote pooled fp32 (+bf16) into SLOT_POOLED / SLOT_POOLED_BF16
+            float* pooled = (float*)cx.slot_ptr(SLOT_POOLED);
+            if (!want_logits)
+                MI355_CHECK_HIP(hipMemcpy2DAsync(out + (size_t)b0 * D, (size_t)D * 4, pooled, (size_t)Dp * 4, (size_t)D * 4,
+                                                 nb, hipMemcpyDeviceToDevice, st));
+            if (pooled_out)
+                MI355_CHECK_HIP(hipMemcpy2DAsync(pooled_out + (size_t)b0 * D, (size_t)D * 4, pooled, (size_t)Dp * 4,
+                                                 (size_t)D * 4, nb, hipMemcpyDeviceToDevice, st));
+        } else {
+            if (features_only) {
+                if (int e = launch_nhwc_to_nchw_f32((const bf16_t*)cx.slot_ptr(d.final_slot),
+                                                    out + (size_t)b0 * D * hw, nb, hw, F.c, D, st))
+                    return e;
+            }
+            const bool need_pool = !features_only || pooled_out;
+            if (need_pool) {
+                float* pooled = (float*)cx.slot_ptr(SLOT_POOLED);   // [nb][Dp]
+                if (int e = launch_gap((const bf16_t*)cx.slot_ptr(d.final_slot), pooled,
+                                       want_logits ? (bf16_t*)cx.slot_ptr(SLOT_POOLED_BF16) : nullptr, nb, hw, F.c, st))
+                    return e;
+                if (!features_only && !want_logits)
+                    MI355_CHECK_HIP(hipMemcpy2DAsync(out + (size_t)b0 * D, (size_t)D * 4, pooled, (size_t)Dp * 4,
+                                                     (size_t)D * 4, nb, hipMemcpyDeviceToDevice, st));
+                if (pooled_out)
+                    MI355_CHECK_HIP(hipMemcpy2DAsync(pooled_out + (size_t)b0 * D, (size_t)D * 4, pooled, (size_t)Dp * 4,
+                                                     (size_t)D * 4, nb, hipMemcpyDeviceToDevice, st));
+            }
+        }
+        if (want_logits) {
+            const Op& c = d.classifier;
+            GemmArgs a{};
+            a.A = (const bf16_t*)cx.slot_ptr(SLOT_POOLED_BF16); a.lda = Dp;
+            a.W = (const bf16_t*)cx.w(c.w_off); a.ldw = (c.cin + 31) & ~31;
+            a.bias = (const float*)cx.w(c.b_off);
+            a.out = out + (size_t)b0 * d.num_classes; a.ldo = d.num_classes; a.out_f32 = 1;
+            a.M = nb; a.N = d.num_classes; a.K = c.cin; a.act = ACT_NONE; a.rows_per_img = 1; a.res_n = a.N;
+            if (int e = launch_gemm_bf16(a, st)) return e;
+        }
+    }
+    return OK;
+}
+
+}  // namespace mi355
+
+namespace mi355 {
+#ifndef MI355_HAVE_SWIN
+int swin_exec(const ModelDef&, const Op&, ExecCtx&) { set_error("swin ops not built"); return ERR_UNSUPPORTED; }
+int swin_pack(Packer&, Op&) { set_error("swin ops not built"); return ERR_UNSUPPORTED; }
+int build_swin_base(ModelDef&) { set_error("swin_base_patch4_window7_224 not built yet"); return ERR_UNSUPPORTED; }
+#endif
+#ifndef MI355_HAVE_REXNET
+int build_rexnet(ModelDef&, double) { set_error("rexnet not built yet"); return ERR_UNSUPPORTED; }
+#endif
+}  // namespace mi355
+
+// ====================================================================================== C ABI
+extern "C" {
+
+int mi355_model_create(const char* name, int num_classes, mi355_model_t* out) {
+    MI355_REQUIRE(name && out, "model_create: null argument");
+    MI355_REQUIRE(num_classes >= 0, "model_create: num_classes=%d must be >= 0", num_classes);
+    mi355_model* m = new mi355_model();
+    m->def.arch = name;
+    m->def.num_classes = num_classes;
+    const std::string n = name;
+    int e;
+    if (n == "efficientnet_b3a" || n == "efficientnet_b3") e = build_efficientnet_b3(m->def);
+    else if (n == "rexnet_100") e = build_rexnet(m->def, 1.0);
+    else if (n == "rexnet_130") e = build_rexnet(m->def, 1.3);
+    else if (n == "rexnet_150") e = build_rexnet(m->def, 1.5);
+    else if (n == "rexnet_200") e = build_rexnet(m->def, 2.0);
+    else if (n == "swin_base_patch4_window7_224") e = build_swin_base(m->def);
+    else {
+        // same wording as the reference's guard (train/train.py:400)
+        set_error("Unknown model name '%s'. Known: efficientnet_b3a, rexnet_100/130/150/200, swin_base_patch4_window7_224", name);
+        e = ERR_ARG;
+    }
+    if (e) { delete m; return e; }
+    *out = m;
+    return OK;
+}
+
+void mi355_model_destroy(mi355_model_t m) {
+    if (!m) return;
+    if (m->dev_blob) (void)hipFree(m->dev_blob);
+    if (m->arena) (void)hipFree(m->arena);
+    for (auto& kv : m->tapbufs)
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    delete m;
+}
+
+int mi355_model_num_tensors(mi355_model_t m) { return m ? (int)m->def.tensors.size() : 0; }
+
+int mi355_model_tensor_info(mi355_model_t m, int i, const char** name, int* ndim, int64_t shape[4], int* kind) {
+    MI355_REQUIRE(m && i >= 0 && i < (int)m->def.tensors.size(), "tensor_info: index %d out of range", i);
+    const TensorSpec& t = m->def.tensors[i];
+    if (name) *name = t.name.c_str();
+    if (ndim) *ndim = (int)t.shape.size();
+    if (shape)
+        for (int d = 0; d < 4; ++d) shape[d] = d < (int)t.shape.size() ? t.shape[d] : 1;
+    if (kind) *kind = t.kind;
+    return OK;
+}
+
+int mi355_model_feature_dim(mi355_model_t m) { return m ? m->def.feat_dim : 0; }
+int mi355_model_num_classes(mi355_model_t m) { return m ? m->def.num_classes : 0; }
+
+int mi355_model_set_tensor(mi355_model_t m, const char* name, const float* host_data, int64_t numel) {
+    MI355_REQUIRE(m && name, "set_tensor: null argument");
+    auto it = m->def.index.find(name);
+    MI355_REQUIRE(it != m->def.index.end(), "set_tensor: unexpected key '%s' for %s", name, m->def.arch.c_str());
+    TensorSpec& t = m->def.tensors[it->second];
+    if (t.kind == 2) return OK;  // int64 buffers carry no arithmetic
+    MI355_REQUIRE(host_data, "set_tensor: null data for '%s'", name);
+    MI355_REQUIRE(numel == t.numel(), "set_tensor: size mismatch for '%s': got %lld elements, expected %lld", name,
+                  (long long)numel, (long long)t.numel());
+    t.data.assign(host_data, host_data + numel);
+    t.set = true;
+    m->packed = false;
+    return OK;
+}
+
+int mi355_model_pack(mi355_model_t m, void* stream) {
+    MI355_REQUIRE(m, "pack: null model");
+    m->blob.clear();
+    Packer pk{m, m->blob};
+    for (Op& op : m->def.ops)
+        if (int e = pack_op(pk, op)) return e;
+    if (m->def.num_classes > 0)
+        if (int e = pack_gemm(pk, m->def.classifier)) return e;
+    const size_t bytes = align_up(m->blob.size(), 256);
+    m->blob.resize(bytes, 0);
+    if (bytes > m->dev_blob_bytes) {
+        if (m->dev_blob) MI355_CHECK_HIP(hipFree(m->dev_blob));
+        m->dev_blob = nullptr;
+        MI355_CHECK_HIP(hipMalloc(&m->dev_blob, bytes));
+        m->dev_blob_bytes = bytes;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    MI355_CHECK_HIP(hipMemcpyAsync(m->dev_blob, m->blob.data(), bytes, hipMemcpyHostToDevice, st));
+    MI355_CHECK_HIP(hipStreamSynchronize(st));  // blob is pageable host memory
+    m->packed = true;
+    return OK;
+}
+
+int mi355_model_forward_features(mi355_model_t m, const float* x, int B, int H, int W, float* out, float* pooled_out,
+                                 void* stream) {
+    return forward_impl(m, x, B, H, W, out, pooled_out, true, (hipStream_t)stream);
+}
+
+int mi355_model_forward(mi355_model_t m, const float* x, int B, int H, int W, float* out, float* pooled_out,
+                        void* stream) {
+    return forward_impl(m, x, B, H, W, out, pooled_out, false, (hipStream_t)stream);
+}
+
+int mi355_model_enable_taps(mi355_model_t m, int enable) {
+    MI355_REQUIRE(m, "enable_taps: null model");
+    m->taps = enable != 0;
+    return OK;
+}
+
+int mi355_model_read_tap(mi355_model_t m, const char* tap_name, float* out, int64_t out_numel, int64_t shape[4],
+                         void* stream) {
+    MI355_REQUIRE(m && tap_name, "read_tap: null argument");
+    auto it = m->tapbufs.find(tap_name);
+    MI355_REQUIRE(it != m->tapbufs.end(), "read_tap: no tap named '%s' was recorded", tap_name);
+    const TapBuf& t = it->second;
+    if (shape) { shape[0] = t.B; shape[1] = t.c_real; shape[2] = t.h; shape[3] = t.w; }
+    if (!out) return OK;
+    MI355_REQUIRE(out_numel >= (int64_t)t.B * t.c_real * t.h * t.w, "read_tap: output too small");
+    return launch_nhwc_to_nchw_f32((const bf16_t*)t.ptr, out, t.B, t.h * t.w, t.c, t.c_real, (hipStream_t)stream);
+}
+
+int mi355_model_set_option(mi355_model_t m, const char* key, int64_t value) {
+    MI355_REQUIRE(m && key, "set_option: null argument");
+    const std::string k = key;
+    if (k == "microbatch") m->microbatch = (int)value;
+    else if (k == "profile") {
+        m->profile = value != 0;
+        for (int i = 0; i < PK_COUNT; ++i) { m->prof_ms[i] = 0; m->prof_launches[i] = 0; }
+    } else {
+        set_error("set_option: unknown option '%s'", key);
+        return ERR_ARG;
+    }
+    return OK;
+}
+
+int mi355_model_profile_read(mi355_model_t m, double* ms_by_kind, int64_t* launches_by_kind, int n) {
+    MI355_REQUIRE(m && ms_by_kind && launches_by_kind && n >= PK_COUNT, "profile_read: need arrays of >= %d", PK_COUNT);
+    for (auto& pe : m->prof_events) {
+        MI355_CHECK_HIP(hipEventSynchronize(pe.second.second));
+        float ms = 0.f;
+        MI355_CHECK_HIP(hipEventElapsedTime(&ms, pe.second.first, pe.second.second));
+        m->prof_ms[pe.first] += ms;
+        m->prof_launches[pe.first] += 1;
+        (void)hipEventDestroy(pe.second.first);
+        (void)hipEventDestroy(pe.second.second);
+    }
+    m->prof_events.clear();
+    for (int i = 0; i < PK_COUNT; ++i) { ms_by_kind[i] = m->prof_ms[i]; launches_by_kind[i] = m->prof_launches[i]; }
+    return OK;
+}
+
+// Layer-granular algorithmic traffic: every conv/dw/1x1 layer reads its input once and
+// writes its output once; BN/act/SE-gate/GAP are epilogues; each residual adds one read of the block input.
+int mi355_model_traffic_kinds(mi355_model_t m, int B, int H, int W, double* bytes_by_kind, double* macs_by_kind, int n) {
+    MI355_REQUIRE(m && bytes_by_kind && macs_by_kind && n >= PK_COUNT, "traffic_kinds: need arrays of >= %d", PK_COUNT);
+    for (int i = 0; i < PK_COUNT; ++i) { bytes_by_kind[i] = 0; macs_by_kind[i] = 0; }
+    plan_slots(m, B, H, W);
+    SlotState S[SLOT_COUNT];
+    for (const Op& op : m->def.ops) {
+        const int kd = prof_kind(op);
+        switch (op.kind) {
+            case OP_STEM: {
+                const int ho = conv_out(H, 3, 2), wo = conv_out(W, 3, 2);
+                S[op.out].h = ho; S[op.out].w = wo;
+                bytes_by_kind[kd] += (double)B * (3.0 * H * W * 4 + (double)ho * wo * op.cout_real * 2);
+                macs_by_kind[kd] += (double)B * ho * wo * op.cout_real * 27;
+                break;
+            }
+            case OP_GEMM: {
+                const double hw = (double)S[op.in].h * S[op.in].w;
+                S[op.out].h = S[op.in].h; S[op.out].w = S[op.in].w;
+                double el = hw * (op.cin_real + op.cout_real);
+                if (op.res != SLOT_NONE) el += hw * (op.res_channels ? op.res_channels : op.cout_real);
+                bytes_by_kind[kd] += B * el * 2;
+                macs_by_kind[kd] += B * hw * op.cin_real * op.cout_real;
+                break;
+            }
+            case OP_DW: {
+                const int ho = conv_out(S[op.in].h, op.k, op.stride), wo = conv_out(S[op.in].w, op.k, op.stride);
+                bytes_by_kind[kd] += (double)B * ((double)S[op.in].h * S[op.in].w + (double)ho * wo) * op.cin_real * 2;
+                macs_by_kind[kd] += (double)B * ho * wo * op.cin_real * op.k * op.k;
+                S[op.out].h = ho; S[op.out].w = wo;
+                break;
+            }
+            case OP_SE:
+                macs_by_kind[kd] += (double)B * 2.0 * op.cin_real * op.rd;
+                break;
+            default: {
+                S[op.out].h = op.tokens_h; S[op.out].w = op.tokens_h;
+                const double t = (double)op.tokens_h * op.tokens_h;
+                bytes_by_kind[kd] += B * t * (op.cin_real + op.cout_real) * 2;
+                break;
+            }
+        }
+    }
+    return OK;
+}
+
+int mi355_model_traffic(mi355_model_t m, int B, int H, int W, double* act_bytes, double* weight_bytes, double* macs) {
+    MI355_REQUIRE(m, "traffic: null model");
+    double by[PK_COUNT], mc[PK_COUNT];
+    if (int e = mi355_model_traffic_kinds(m, B, H, W, by, mc, PK_COUNT)) return e;
+    double tb = 0, tm = 0;
+    for (int i = 0; i < PK_COUNT; ++i) { tb += by[i]; tm += mc[i]; }
+    if (act_bytes) *act_bytes = tb;
+    if (macs) *macs = tm;
+    if (weight_bytes) *weight_bytes = (double)m->blob.size();
+    return OK;
+}
+
+int mi355_conv_input_silu(const float* x, const float* w, int B, int H, int W, float* out, void* stream) {
+    MI355_REQUIRE(x && w && out, "conv_input_silu: null pointer");
+    MI355_REQUIRE(B >= 1 && H >= 1 && W >= 1, "conv_input_silu: bad shape");
+    return launch_conv_input_silu(x, w, B, H, W, out, (hipStream_t)stream);
+}
+
+}  // extern "C"

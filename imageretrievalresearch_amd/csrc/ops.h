@@ -1,0 +1,53 @@
+// Internal launcher interface between the model executor (model.hip) and the kernel files.
+// All tensors are device pointers; activations are NHWC bf16 with the channel count a multiple of 8.
+#pragma once
+#include "common.h"
+
+namespace mi355 {
+
+// ---- 1x1 conv / linear as a bf16 MFMA GEMM (gemm_bf16.hip) -------------------------------------
+//   out[m][n] = act( sum_k A'[m][k] * W[n][k] + bias[n] ) (+ res[m][n])
+//   A'[m][k]  = a_relu6 ? relu6(A[m][k] * gate) : A[m][k] * gate,   gate = gate[m / rows_per_img][k] or 1
+// W is [Npad][ldw] bf16 with ldw = K rounded up to 32 and zero padding (rows up to Npad = N rounded up to 16),
+// bias is fp32 [Npad].
+struct GemmArgs {
+    const bf16_t* A; int lda;
+    const bf16_t* W; int ldw;
+    const float* bias;
+    const bf16_t* res; int ldr; int res_n;   // residual added to outputs n < res_n (rexnet: first cin channels)
+    const float* gate; int gate_ld; int rows_per_img;
+    void* out; int ldo; int out_f32;
+    int M, N, K;
+    int act;
+    int a_relu6;
+};
+int launch_gemm_bf16(const GemmArgs& a, hipStream_t st);
+
+// ---- convolution-side kernels (conv_kernels.hip) -----------------------------------------------
+// Stem: x [B][3][H][W] fp32 NCHW -> out [B][Ho][Wo][Cout] bf16, 3x3 stride 2 pad 1, + bias + act.
+// w [3*3*3][Cout] fp32 laid out (ky, kx, ci) major, bias fp32 [Cout].
+int launch_stem(const float* x, const float* w, const float* bias, bf16_t* out, int B, int H, int W, int Cout,
+                int act, hipStream_t st);
+
+// Depthwise k x k (k = 3 or 5), stride 1 or 2, pad k/2.  w [k*k][C] bf16, bias fp32 [C].
+// pool_partial (optional): [B][dw_pool_blocks(...)][C] fp32 partial sums of the un-rounded output
+// (the SE squeeze), reduced in a fixed order.
+int dw_pool_blocks(int Ho, int Wo, int C);
+int launch_dwconv(const bf16_t* in, const bf16_t* w, const float* bias, bf16_t* out, float* pool_partial, int B,
+                  int H, int W, int C, int k, int stride, int act, hipStream_t st);
+
+// Squeeze-excite gate: s = (sum over nblk partials) / hw ; r = act1(W1 s + b1) ; gate = sigmoid(W2 r + b2).
+// W1 [rd][C] fp32, W2 [C][rd] fp32.  gate out [B][C] fp32.
+int launch_se(const float* pool_partial, int nblk, float inv_hw, const float* w1, const float* b1, const float* w2,
+              const float* b2, float* gate, int B, int C, int rd, int act1, hipStream_t st);
+
+// Global average pool of NHWC bf16 -> pooled fp32 [B][C] (+ optional bf16 copy for the classifier GEMM).
+int launch_gap(const bf16_t* in, float* pooled, bf16_t* pooled_bf16, int B, int HW, int C, hipStream_t st);
+
+// NHWC bf16 [B][HW][C] -> NCHW fp32 [B][Cvalid][HW] (forward_features output, taps).
+int launch_nhwc_to_nchw_f32(const bf16_t* in, float* out, int B, int HW, int C, int Cvalid, hipStream_t st);
+
+// conv_input pre-stem: SiLU(conv3x3 s1 p1, 3->3, no bias), fp32 NCHW in/out.
+int launch_conv_input_silu(const float* x, const float* w, int B, int H, int W, float* out, hipStream_t st);
+
+}  // namespace mi355

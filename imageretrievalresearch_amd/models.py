@@ -1,0 +1,350 @@
+"""timm-shaped model objects backed by libmi355_retrieval.
+
+``create_model(name, pretrained=False, num_classes=1000)`` mirrors ``timm.create_model`` for the four
+backbones the reference uses (inference/inference.py:102,110,133,146 ; train/train.py:396 ;
+train/train_vit_triplet.py:354).  The returned ``nn.Module`` exposes the timm 0.4.12 surface the
+reference touches:
+
+* ``model(x)`` / ``model.forward_features(x)``; ``.eval() .train() .to() .parameters()``
+* timm state-dict keys (``load_state_dict(strict=True|False)``), so Lightning checkpoints with the
+  ``model.`` prefix stripped load unchanged (inference/inference.py:117-124)
+* assignable heads: ``model.classifier`` (efficientnet), ``model.head`` / ``model.head.fc`` (rexnet),
+  ``model.head`` (swin); ``model.head = Identity()`` (train_vit_triplet.py:357) and
+  ``model.classifier = Linear(...)`` (inference.py:141) are honoured at the next forward.
+
+The parameter table (names, shapes, order) comes from the C library, which owns the architecture
+definitions; Python only mirrors it as ``nn.Parameter``s.  The forward pass is inference-only
+(the reference's hot path runs under ``torch.no_grad``): it launches the HIP kernels on torch's
+current stream and returns tensors without autograd history.  There is no torch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from ._lib import MI355Error, check, lib, require_cuda, stream_ptr
+
+_FAMILY = {
+    "efficientnet_b3a": "efficientnet", "efficientnet_b3": "efficientnet",
+    "rexnet_100": "rexnet", "rexnet_130": "rexnet", "rexnet_150": "rexnet", "rexnet_200": "rexnet",
+    "swin_base_patch4_window7_224": "swin",
+}
+_HEAD_PATH = {"efficientnet": "classifier", "rexnet": "head.fc", "swin": "head"}
+
+
+def list_models():
+    return sorted(_FAMILY)
+
+
+class _Node(nn.Module):
+    """Structural container so dotted timm keys map onto real submodules."""
+
+
+class ClassifierHead(nn.Module):
+    """timm's rexnet ``ClassifierHead``: global-avg-pool + fc; callable on the un-pooled map
+    (train/train.py:195 ``self.model.head(fm)``).  Stand-alone calls use torch ops; inside
+    ``model(x)`` the pooled GEMM runs in the HIP path."""
+
+    def __init__(self, in_features, num_classes):
+        super().__init__()
+        self.fc = nn.Linear(in_features, num_classes) if num_classes > 0 else nn.Identity()
+
+    def forward(self, x):
+        if x.dim() == 4:
+            x = x.mean((2, 3))
+        return self.fc(x)
+
+
+def _table(handle):
+    L = lib()
+    out = []
+    name = C.c_char_p()
+    ndim = C.c_int()
+    shape = (C.c_int64 * 4)()
+    kind = C.c_int()
+    for i in range(L.mi355_model_num_tensors(handle)):
+        check(L.mi355_model_tensor_info(handle, i, C.byref(name), C.byref(ndim), shape, C.byref(kind)))
+        out.append((name.value.decode(), tuple(shape[d] for d in range(ndim.value)), kind.value))
+    return out
+
+
+def _new_handle(name: str, num_classes: int):
+    h = C.c_void_p()
+    check(lib().mi355_model_create(name.encode(), int(num_classes), C.byref(h)))
+    return h
+
+
+class MI355Model(nn.Module):
+    def __init__(self, model_name: str, num_classes: int = 1000, seed: int = 0):
+        super().__init__()
+        if model_name not in _FAMILY:
+            # same guard wording as the reference (train/train.py:400)
+            raise AssertionError(f"Unknown model name {model_name!r}; known: {list_models()}")
+        self.model_name = model_name
+        self.family = _FAMILY[model_name]
+        self.__dict__["_handle"] = None
+        self.__dict__["_handle_classes"] = None
+        self.__dict__["_dirty"] = True
+        self.__dict__["_sig"] = None
+        self.__dict__["_pack_device"] = None
+        handle = _new_handle(model_name, num_classes)
+        self.__dict__["_handle"] = handle
+        self.__dict__["_handle_classes"] = num_classes
+        self.num_features = lib().mi355_model_feature_dim(handle)
+        self.num_classes = num_classes
+        head_prefix = _HEAD_PATH[self.family] + "."
+        for name, shape, kind in _table(handle):
+            if name.startswith(head_prefix):
+                continue  # the classifier is a real nn.Linear, created below
+            parts = name.split(".")
+            mod = self
+            for p in parts[:-1]:
+                if p not in mod._modules:
+                    mod.add_module(p, _Node())
+                mod = mod._modules[p]
+            if kind == 0:
+                mod.register_parameter(parts[-1], nn.Parameter(torch.zeros(shape)))
+            elif kind == 1:
+                mod.register_buffer(parts[-1], torch.zeros(shape))
+            else:
+                mod.register_buffer(parts[-1], torch.zeros(shape, dtype=torch.int64))
+        D = self.num_features
+        if self.family == "efficientnet":
+            self.classifier = nn.Linear(D, num_classes) if num_classes > 0 else nn.Identity()
+        elif self.family == "rexnet":
+            self.head = ClassifierHead(D, num_classes)
+        else:
+            self.head = nn.Linear(D, num_classes) if num_classes > 0 else nn.Identity()
+        self.reset_parameters(seed)
+
+    # ------------------------------------------------------------------ init
+    @torch.no_grad()
+    def reset_parameters(self, seed: int = 0):
+        """Seeded random init (there are no downloadable weights offline): conv/linear N(0, 2/fan_in),
+        norm scales 1, shifts 0, running stats (0, 1)."""
+        g = torch.Generator().manual_seed(seed)
+        for name, t in list(self.named_parameters()) + list(self.named_buffers()):
+            if t.dtype != torch.float32:
+                if name.endswith("relative_position_index"):
+                    continue
+                t.zero_()
+                continue
+            leaf = name.rsplit(".", 1)[-1]
+            if leaf == "running_var":
+                t.fill_(1.0)
+            elif leaf in ("running_mean", "bias"):
+                t.zero_()
+            elif leaf == "relative_position_bias_table":
+                t.copy_(torch.randn(t.shape, generator=g) * 0.02)
+            elif t.dim() >= 2:
+                fan_in = t[0].numel()
+                t.copy_(torch.randn(t.shape, generator=g) * math.sqrt(2.0 / fan_in))
+            else:  # norm weight
+                t.fill_(1.0)
+        self._dirty = True
+
+    # ------------------------------------------------------------------ dirty tracking
+    def _apply(self, fn, *a, **k):
+        self.__dict__["_dirty"] = True
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        self.__dict__["_dirty"] = True
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def __setattr__(self, name, value):
+        if name in ("classifier", "head"):
+            self.__dict__["_dirty"] = True
+        super().__setattr__(name, value)
+
+    def mark_dirty(self):
+        """Call after modifying parameters in place in eval mode (train mode re-checks every call)."""
+        self._dirty = True
+
+    def _head_linear(self):
+        mod = self
+        for p in _HEAD_PATH[self.family].split("."):
+            mod = getattr(mod, p, None)
+            if mod is None:
+                return None
+        return mod if isinstance(mod, nn.Linear) else None
+
+    def _signature(self):
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+
+    def _pack(self, device):
+        L = lib()
+        fc = self._head_linear()
+        ncls = fc.out_features if fc is not None else 0
+        if fc is not None and fc.in_features != self.num_features:
+            raise MI355Error(f"classifier expects {fc.in_features} features, backbone gives {self.num_features}")
+        if self._handle_classes != ncls:
+            L.mi355_model_destroy(self._handle)
+            self.__dict__["_handle"] = _new_handle(self.model_name, ncls)
+            self.__dict__["_handle_classes"] = ncls
+        self.num_classes = ncls
+        sd = self.state_dict()
+        head_prefix = _HEAD_PATH[self.family] + "."
+        for name, shape, kind in _table(self._handle):
+            if kind == 2:
+                continue
+            if name not in sd:
+                raise MI355Error(f"state dict has no tensor {name!r}")
+            t = sd[name].detach().to("cpu", torch.float32).contiguous()
+            if tuple(t.shape) != tuple(shape) and not (name.startswith(head_prefix)):
+                raise MI355Error(f"{name}: shape {tuple(t.shape)} != expected {tuple(shape)}")
+            check(L.mi355_model_set_tensor(self._handle, name.encode(), t.data_ptr(), t.numel()))
+        with torch.cuda.device(device):
+            check(L.mi355_model_pack(self._handle, stream_ptr(device)))
+        self.__dict__["_dirty"] = False
+        self.__dict__["_pack_device"] = device
+        self.__dict__["_sig"] = self._signature()
+
+    def _ensure_packed(self, device):
+        if self._dirty or self._pack_device != device:
+            self._pack(device)
+        elif self.training and self._sig != self._signature():
+            self._pack(device)
+
+    # ------------------------------------------------------------------ options / introspection
+    def set_option(self, key: str, value: int):
+        check(lib().mi355_model_set_option(self._handle, key.encode(), int(value)))
+        return self
+
+    def traffic(self, B: int, H: int = 224, W: int = 224):
+        """Algorithmic bytes / MACs of one forward (layer-granular model)."""
+        a, w, m = C.c_double(), C.c_double(), C.c_double()
+        check(lib().mi355_model_traffic(self._handle, B, H, W, C.byref(a), C.byref(w), C.byref(m)))
+        by = (C.c_double * 8)()
+        mc = (C.c_double * 8)()
+        check(lib().mi355_model_traffic_kinds(self._handle, B, H, W, by, mc, 8))
+        kinds = ["stem", "gemm", "dw", "se", "other", "attn", "ln"]
+        return {"act_bytes": a.value, "weight_bytes": w.value, "macs": m.value,
+                "bytes_by_kind": dict(zip(kinds, list(by))), "macs_by_kind": dict(zip(kinds, list(mc)))}
+
+    def profile_read(self):
+        ms = (C.c_double * 8)()
+        n = (C.c_int64 * 8)()
+        check(lib().mi355_model_profile_read(self._handle, ms, n, 8))
+        kinds = ["stem", "gemm", "dw", "se", "other", "attn", "ln"]
+        return {k: {"ms": ms[i], "launches": n[i]} for i, k in enumerate(kinds)}
+
+    def enable_taps(self, on: bool = True):
+        check(lib().mi355_model_enable_taps(self._handle, int(on)))
+        return self
+
+    def read_tap(self, name: str) -> torch.Tensor:
+        shape = (C.c_int64 * 4)()
+        check(lib().mi355_model_read_tap(self._handle, name.encode(), None, 0, shape, None))
+        out = torch.empty(tuple(shape), dtype=torch.float32, device=self._pack_device)
+        with torch.cuda.device(out.device):
+            check(lib().mi355_model_read_tap(self._handle, name.encode(), out.data_ptr(), out.numel(), shape,
+                                             stream_ptr(out.device)))
+        return out
+
+    # ------------------------------------------------------------------ forward
+    def _prep(self, x):
+        require_cuda(x, "model input")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise MI355Error(f"expected (B,3,H,W) input, got {tuple(x.shape)}")
+        x = x.detach()
+        if x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        self._ensure_packed(x.device)
+        return x
+
+    def forward_features(self, x: torch.Tensor) -> torch.Tensor:
+        """timm ``forward_features``: un-pooled (B,C,H/32,W/32) for efficientnet/rexnet, pooled (B,C) for swin."""
+        x = self._prep(x)
+        B, _, H, W = x.shape
+        D = self.num_features
+        if self.family == "swin":
+            out = torch.empty((B, D), dtype=torch.float32, device=x.device)
+        else:
+            out = torch.empty((B, D, (H + 31) // 32, (W + 31) // 32), dtype=torch.float32, device=x.device)
+        if B:
+            with torch.cuda.device(x.device):
+                check(lib().mi355_model_forward_features(self._handle, x.data_ptr(), B, H, W, out.data_ptr(), None,
+                                                         stream_ptr(x.device)))
+        return out
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = self._prep(x)
+        B, _, H, W = x.shape
+        n = self.num_classes if self.num_classes > 0 else self.num_features
+        out = torch.empty((B, n), dtype=torch.float32, device=x.device)
+        if B:
+            with torch.cuda.device(x.device):
+                check(lib().mi355_model_forward(self._handle, x.data_ptr(), B, H, W, out.data_ptr(), None,
+                                                stream_ptr(x.device)))
+        # a head that is neither Linear nor Identity (user-assigned module): apply it on the pooled features
+        head = self
+        for p in _HEAD_PATH[self.family].split("."):
+            head = getattr(head, p)
+        if not isinstance(head, (nn.Linear, nn.Identity)):
+            out = head(out)
+        return out
+
+    def embed(self, x: torch.Tensor):
+        """Pooled embeddings (B, D) regardless of the head — ``get_fm(forward_features(x))`` of
+        train/train.py:84-103 in one call — plus the logits when a classifier is attached."""
+        x = self._prep(x)
+        B, _, H, W = x.shape
+        D = self.num_features
+        pooled = torch.empty((B, D), dtype=torch.float32, device=x.device)
+        n = self.num_classes if self.num_classes > 0 else D
+        out = torch.empty((B, n), dtype=torch.float32, device=x.device)
+        if B:
+            with torch.cuda.device(x.device):
+                check(lib().mi355_model_forward(self._handle, x.data_ptr(), B, H, W, out.data_ptr(),
+                                                pooled.data_ptr(), stream_ptr(x.device)))
+        return pooled, (out if self.num_classes > 0 else None)
+
+    def __del__(self):
+        h = self.__dict__.get("_handle")
+        if h is not None:
+            try:
+                lib().mi355_model_destroy(h)
+            except Exception:
+                pass
+
+
+def create_model(model_name: str, pretrained: bool = False, num_classes: int = 1000, seed: int = 0, **kwargs):
+    """``timm.create_model`` for the reference's backbones.  ``pretrained=True`` would fetch ImageNet
+    weights from the network in timm (train/train.py:396); there is no network here, so it raises."""
+    if pretrained:
+        raise MI355Error("pretrained=True needs a download, which is unavailable offline; create the model with "
+                         "pretrained=False and load a checkpoint with load_state_dict")
+    if kwargs:
+        raise TypeError(f"unsupported create_model arguments: {sorted(kwargs)}")
+    return MI355Model(model_name, num_classes=num_classes, seed=seed)
+
+
+class ConvInput(nn.Sequential):
+    """The reference's pre-stem ``Sequential(Conv2d(3,3,3,1,1,bias=False), SiLU)``
+    (inference/inference.py:103-104) with the same state-dict keys, run as one HIP kernel."""
+
+    def __init__(self):
+        super().__init__(nn.Conv2d(3, 3, kernel_size=(3, 3), stride=(1, 1), padding=(1, 1), bias=False),
+                         nn.SiLU(inplace=True))
+
+    def forward(self, x):
+        require_cuda(x, "conv_input input")
+        x = x.detach().float().contiguous()
+        w = self[0].weight.detach().float().contiguous()
+        out = torch.empty_like(x)
+        B, _, H, W = x.shape
+        if B:
+            with torch.cuda.device(x.device):
+                check(lib().mi355_conv_input_silu(x.data_ptr(), w.data_ptr(), B, H, W, out.data_ptr(),
+                                                  stream_ptr(x.device)))
+        return out
+
+
+def with_conv_input(base_model: nn.Module) -> nn.Sequential:
+    """``Sequential(conv_layer, base_model)`` of inference/inference.py:105 (keys ``0.0.weight``, ``1.*``)."""
+    return nn.Sequential(ConvInput(), base_model)

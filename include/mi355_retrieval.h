@@ -155,6 +155,16 @@ int mi355_model_read_tap(mi355_model_t m, const char* tap_name, float* out, int6
 int mi355_model_traffic(mi355_model_t m, int B, int H, int W, double* act_bytes, double* weight_bytes,
                         double* macs);
 
+/* Per-kernel-family view of the same model, for the roofline of the dominant kernel.  Arrays of n >= 8
+ * doubles indexed by kind: 0 stem, 1 1x1-conv GEMM, 2 depthwise, 3 SE, 4 other, 5 window attention, 6 layernorm. */
+int mi355_model_traffic_kinds(mi355_model_t m, int B, int H, int W, double* bytes_by_kind, double* macs_by_kind, int n);
+
+/* Executor options: "microbatch" (images per pass through the layer plan; 0 = whole batch),
+ * "profile" (1 = bracket every op with hipEvents on the launch stream; resets the accumulators). */
+int mi355_model_set_option(mi355_model_t m, const char* key, int64_t value);
+/* Accumulated per-kind kernel time (ms) and launch counts since "profile" was enabled; synchronises. */
+int mi355_model_profile_read(mi355_model_t m, double* ms_by_kind, int64_t* launches_by_kind, int n);
+
 /* conv_input pre-stem (inference/inference.py:103-105): out = SiLU(Conv2d(3,3,3,1,1,bias=False)(x)),
  * x/out [B][3][H][W] fp32 NCHW, w [3][3][3][3] fp32 (device). */
 int mi355_conv_input_silu(const float* x, const float* w, int B, int H, int W, float* out, void* stream);
