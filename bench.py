@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Headline benchmark: EfficientNet-B3a embed + cosine top-k over a 100k-row gallery (BASELINE.json).
+
+One step = one pass of the hot path over one batch: embed 256 synthetic 224x224 images per GPU
+(bf16 activations, fp32 accumulate) and rank the resulting 256 embeddings per GPU (k=3, fp32) against a
+100 000 x 1536 gallery resident in HBM.  With N > 1 ranks (one process per GPU, torchrun) the gallery is
+row-sharded 100000/N rows per GPU and the rank step is all-gather(queries) -> local top-k ->
+all-gather(candidates) -> merge; images per GPU are fixed, so scaling is weak.
+
+Prints ONE JSON line on rank 0 (contract in the task brief) carrying `roofline` (dominant kernel family,
+timed live with hipEvents on the launch stream) and `cpu_baseline` (the CPU oracle = a port of the
+reference's CPU path, timed on a bounded sample on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import imageretrievalresearch_amd as M  # noqa: E402
+from imageretrievalresearch_amd import synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+D = 1536
+GALLERY_ROWS = 100_000
+BATCH = 256
+TOPK = 3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--gallery", type=int, default=GALLERY_ROWS)
+    ap.add_argument("--microbatch", type=int, default=int(os.environ.get("MI355_MICROBATCH", "0")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="efficientnet_b3a")
+    return ap.parse_args()
+
+
+def cpu_baseline(model_name, gallery_rows):
+    """Reference-style CPU path on a bounded sample (about 10-30 s): the oracle's fp32 forward on 16
+    images (BASELINE configs[0] batch) and the per-query CosineSimilarity+topk loop of train/train.py:250-251
+    for 8 queries against the same-size gallery."""
+    from oracle import effnet, rank as orank
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    sd = effnet.init_state_dict(2, num_classes=0)
+    x = torch.from_numpy(synth.uniform(1, (16, 3, 224, 224)))
+    with torch.no_grad():
+        effnet.forward(sd, x[:2])                      # warm-up
+        t0 = time.perf_counter()
+        emb = effnet.forward(sd, x)
+        t_embed = (time.perf_counter() - t0) / 16
+    rows = min(gallery_rows, 100_000)
+    g = torch.from_numpy(synth.normal(5, (rows, D)))
+    q = torch.from_numpy(synth.normal(13, (8, D)))
+    orank.rank_reference_loop(q[:1], g, TOPK)
+    t0 = time.perf_counter()
+    orank.rank_reference_loop(q, g, TOPK)
+    t_rank = (time.perf_counter() - t0) / 8 * (gallery_rows / rows)
+    del emb
+    return {"value": 1.0 / (t_embed + t_rank), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 forward on 16 images ({t_embed * 1e3:.1f} ms/img) + reference-style "
+                      f"cos+topk loop for 8 queries vs {rows} rows ({t_rank * 1e3:.1f} ms/query); torch "
+                      f"{torch.__version__} CPU, {cores} threads",
+            "embed_images_per_s": 1.0 / t_embed, "rank_queries_per_s": 1.0 / t_rank}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        a.gpus = world
+    dist = torch.distributed
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- resident inputs (timed region starts with everything in HBM)
+    model = M.create_model(a.model, num_classes=0, seed=0).to(dev).eval()
+    if a.microbatch:
+        model.set_option("microbatch", a.microbatch)
+    x = M.synth_fill(a.batch * 3 * 224 * 224, 1000 + rank, synth.UNIFORM, dev).view(a.batch, 3, 224, 224)
+    lo = a.gallery * rank // world
+    hi = a.gallery * (rank + 1) // world
+    shard = M.synth_fill((hi - lo) * D, 5, synth.NORMAL, dev, offset=lo * D).view(hi - lo, D)
+    gal = M.ShardedGallery(shard)
+    del shard
+
+    def step():
+        emb = model(x)
+        return gal.search(emb, TOPK)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / a.steps * 1e3
+    images_per_s = a.batch * world * a.steps / dt
+    assert out[1].shape == (a.batch * world, TOPK)
+
+    result = None
+    if rank == 0:
+        # ---- side measurements on rank 0 (not part of `value`)
+        def timeit(fn, n):
+            fn()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n
+
+        n_side = max(3, min(a.steps, 20))
+        t_embed = timeit(lambda: model(x), n_side)
+        q = M.synth_fill(a.batch * D, 13, synth.NORMAL, dev).view(a.batch, D)
+        t_rank = timeit(lambda: gal.ops.local_topk(q, gal.local, TOPK, 0), n_side)
+
+        # ---- roofline of the dominant kernel family: hipEvents around every launch, on the launch stream
+        model.set_option("profile", 1)
+        for _ in range(3):
+            model(x)
+        prof = model.profile_read()
+        model.set_option("profile", 0)
+        tr = model.traffic(a.batch)
+        fam = max(("gemm", "dw", "stem", "se", "attn", "ln", "other"), key=lambda k: prof[k]["ms"])
+        launches = max(1, prof[fam]["launches"])
+        avg_ms = prof[fam]["ms"] / launches
+        bytes_per_launch = tr["bytes_by_kind"][fam] / (launches / 3)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        kernel_names = {"gemm": "k_gemm_bf16 (1x1 conv)", "dw": "k_dwconv (depthwise + SE squeeze)",
+                        "stem": "k_stem", "se": "k_se", "attn": "k_win_attn", "ln": "k_layernorm", "other": "other"}
+        roofline = {"bound": "hbm", "kernel": kernel_names[fam], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                    "family_ms_per_forward": {k: v["ms"] / 3 for k, v in prof.items() if v["launches"]}}
+        embed_gbs = (tr["act_bytes"] + tr["weight_bytes"]) / t_embed / 1e9
+        result = {
+            "metric": "images/sec embed + queries/sec top-k@100k-gallery, EffNet-B3a 224^2",
+            "value": images_per_s, "unit": "images/s (each image embedded and ranked as a query)",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"{a.model} bf16 embed bs={a.batch}/GPU 224x224 + cosine top-{TOPK} of the "
+                                   f"{a.batch * world} embeddings vs {a.gallery}x{D} fp32 gallery "
+                                   f"(row-sharded over {world} GPU)", "batch_per_gpu": a.batch,
+                       "gallery_rows": a.gallery, "dim": D, "k": TOPK, "microbatch": a.microbatch,
+                       "parallelism": f"dp{world} + row-sharded gallery"},
+            "embed_images_per_s_1gpu": a.batch / t_embed,
+            "rank_queries_per_s_1gpu_shard": a.batch / t_rank,
+            "embed_roofline": {"algorithmic_GBps": embed_gbs, "frac_of_8TBps": embed_gbs / HBM_PEAK_GBS,
+                               "act_MB_per_img": tr["act_bytes"] / a.batch / 1e6,
+                               "gflop_per_img": 2 * tr["macs"] / a.batch / 1e9},
+            "rank_roofline": {"bound": "mfma-f32", "tflops": 2.0 * a.batch * (hi - lo) * D / t_rank / 1e12,
+                              "peak_tflops": 157.3},
+            "roofline": roofline,
+        }
+        if not a.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(a.model, a.gallery)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -58,7 +58,9 @@ struct mi355_model {
     std::map<std::string, TapBuf> tapbufs;
     // per-kind profiling with hipEvents (option "profile")
     bool profile = false;
-    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;  // (op index, events)
+    std::vector<double> prof_op_ms;
+    std::vector<long> prof_op_n;
     double prof_ms[PK_COUNT] = {0};
     long prof_launches[PK_COUNT] = {0};
 };
@@ -356,7 +358,9 @@ static int run_backbone(ExecCtx& cx) {
     // NOTE: slot dims for DW/SE depend on walk order; plan_slots() left the LAST writer's dims in each
     // slot, so re-derive dims incrementally while executing.
     SlotState* S = m->slots;
+    int op_index = -1;
     for (const Op& op : m->def.ops) {
+        ++op_index;
         switch (op.kind) {
             case OP_STEM: S[op.out].h = conv_out(cx.H, 3, 2); S[op.out].w = conv_out(cx.W, 3, 2); S[op.out].c = op.cout; break;
             case OP_GEMM: S[op.out].h = S[op.in].h; S[op.out].w = S[op.in].w; S[op.out].c = op.cout; break;
@@ -377,7 +381,7 @@ static int run_backbone(ExecCtx& cx) {
         if (int e = exec_op(cx, op)) return e;
         if (m->profile) {
             MI355_CHECK_HIP(hipEventRecord(e1, cx.st));
-            m->prof_events.push_back({prof_kind(op), {e0, e1}});
+            m->prof_events.push_back({op_index, {e0, e1}});
         }
         if (m->taps && !op.tap.empty())
             if (int e = record_tap(cx, op)) return e;
@@ -585,6 +589,8 @@ int mi355_model_set_option(mi355_model_t m, const char* key, int64_t value) {
     else if (k == "profile") {
         m->profile = value != 0;
         for (int i = 0; i < PK_COUNT; ++i) { m->prof_ms[i] = 0; m->prof_launches[i] = 0; }
+        m->prof_op_ms.assign(m->def.ops.size(), 0.0);
+        m->prof_op_n.assign(m->def.ops.size(), 0);
     } else {
         set_error("set_option: unknown option '%s'", key);
         return ERR_ARG;
@@ -598,14 +604,71 @@ int mi355_model_profile_read(mi355_model_t m, double* ms_by_kind, int64_t* launc
         MI355_CHECK_HIP(hipEventSynchronize(pe.second.second));
         float ms = 0.f;
         MI355_CHECK_HIP(hipEventElapsedTime(&ms, pe.second.first, pe.second.second));
-        m->prof_ms[pe.first] += ms;
-        m->prof_launches[pe.first] += 1;
+        const int kd = prof_kind(m->def.ops[pe.first]);
+        m->prof_ms[kd] += ms;
+        m->prof_launches[kd] += 1;
+        if (m->prof_op_ms.size() < m->def.ops.size()) { m->prof_op_ms.resize(m->def.ops.size(), 0.0); m->prof_op_n.resize(m->def.ops.size(), 0); }
+        m->prof_op_ms[pe.first] += ms;
+        m->prof_op_n[pe.first] += 1;
         (void)hipEventDestroy(pe.second.first);
         (void)hipEventDestroy(pe.second.second);
     }
     m->prof_events.clear();
     for (int i = 0; i < PK_COUNT; ++i) { ms_by_kind[i] = m->prof_ms[i]; launches_by_kind[i] = m->prof_launches[i]; }
     return OK;
+}
+
+// Per-op view of the profile + traffic model: for op i (plan order) the average launch time (ms), its
+// algorithmic bytes at batch B, its kind and a short label.  Call after mi355_model_profile_read.
+int mi355_model_profile_ops(mi355_model_t m, int B, int H, int W, int max_ops, double* avg_ms, double* bytes,
+                            int* kinds, char* labels, int label_stride) {
+    MI355_REQUIRE(m && avg_ms && bytes && kinds, "profile_ops: null argument");
+    const int n = (int)m->def.ops.size();
+    MI355_REQUIRE(max_ops >= n, "profile_ops: need room for %d ops", n);
+    SlotState S[SLOT_COUNT];
+    for (int i = 0; i < n; ++i) {
+        const Op& op = m->def.ops[i];
+        avg_ms[i] = (i < (int)m->prof_op_n.size() && m->prof_op_n[i]) ? m->prof_op_ms[i] / m->prof_op_n[i] : 0.0;
+        kinds[i] = prof_kind(op);
+        double by = 0;
+        char lab[128] = "";
+        switch (op.kind) {
+            case OP_STEM: {
+                const int ho = conv_out(H, 3, 2), wo = conv_out(W, 3, 2);
+                S[op.out].h = ho; S[op.out].w = wo;
+                by = (double)B * (3.0 * H * W * 4 + (double)ho * wo * op.cout_real * 2);
+                snprintf(lab, sizeof lab, "stem 3->%d @%dx%d", op.cout_real, ho, wo);
+                break;
+            }
+            case OP_GEMM: {
+                const double hw = (double)S[op.in].h * S[op.in].w;
+                S[op.out].h = S[op.in].h; S[op.out].w = S[op.in].w;
+                double el = hw * (op.cin_real + op.cout_real);
+                if (op.res != SLOT_NONE) el += hw * (op.res_channels ? op.res_channels : op.cout_real);
+                by = B * el * 2;
+                snprintf(lab, sizeof lab, "pw %d->%d @%dx%d%s%s", op.cin_real, op.cout_real, S[op.in].h, S[op.in].w,
+                         op.use_gate ? " gate" : "", op.res != SLOT_NONE ? " res" : "");
+                break;
+            }
+            case OP_DW: {
+                const int ho = conv_out(S[op.in].h, op.k, op.stride), wo = conv_out(S[op.in].w, op.k, op.stride);
+                by = (double)B * ((double)S[op.in].h * S[op.in].w + (double)ho * wo) * op.cin_real * 2;
+                snprintf(lab, sizeof lab, "dw k%d s%d C%d @%dx%d", op.k, op.stride, op.cin_real, S[op.in].h, S[op.in].w);
+                S[op.out].h = ho; S[op.out].w = wo;
+                break;
+            }
+            case OP_SE: snprintf(lab, sizeof lab, "se C%d rd%d", op.cin_real, op.rd); break;
+            default: {
+                S[op.out].h = op.tokens_h; S[op.out].w = op.tokens_h;
+                by = (double)B * op.tokens_h * op.tokens_h * (op.cin_real + op.cout_real) * 2;
+                snprintf(lab, sizeof lab, "op%d C%d->%d t%d", (int)op.kind, op.cin_real, op.cout_real, op.tokens_h);
+                break;
+            }
+        }
+        bytes[i] = by;
+        if (labels && label_stride > 0) { strncpy(labels + (size_t)i * label_stride, lab, label_stride - 1); labels[(size_t)i * label_stride + label_stride - 1] = 0; }
+    }
+    return n;
 }
 
 // Layer-granular algorithmic traffic: every conv/dw/1x1 layer reads its input once and

@@ -232,6 +232,17 @@ class MI355Model(nn.Module):
         kinds = ["stem", "gemm", "dw", "se", "other", "attn", "ln"]
         return {k: {"ms": ms[i], "launches": n[i]} for i, k in enumerate(kinds)}
 
+    def profile_ops(self, B: int, H: int = 224, W: int = 224):
+        """Per-op table [(label, kind, avg_ms, algorithmic_bytes)] after ``profile_read()``."""
+        n = 1024
+        ms = (C.c_double * n)()
+        by = (C.c_double * n)()
+        kd = (C.c_int * n)()
+        lab = C.create_string_buffer(n * 64)
+        cnt = lib().mi355_model_profile_ops(self._handle, B, H, W, n, ms, by, kd, lab, 64)
+        kinds = ["stem", "gemm", "dw", "se", "other", "attn", "ln"]
+        return [(lab.raw[i * 64:(i + 1) * 64].split(b"\0")[0].decode(), kinds[kd[i]], ms[i], by[i]) for i in range(cnt)]
+
     def enable_taps(self, on: bool = True):
         check(lib().mi355_model_enable_taps(self._handle, int(on)))
         return self

@@ -1,0 +1,117 @@
+"""Row-sharded gallery across the GPUs of one node.
+
+One process per GPU (``torch.distributed``; backend "nccl" is RCCL on ROCm, xGMI underneath).
+The reference has no multi-GPU inference path (inference/inference.py:271 is single-device); this is
+the one place the hot path has a real exchange step:
+
+  1. every rank embeds its own images -> its gallery shard is *born* local, rows
+     ``[offset[r], offset[r+1])`` of the global gallery; no collective during embedding
+  2. queries are replicated with one all-gather of (Q_local, D) fp32 (1.5 MB at Q=256)
+  3. each rank runs the fused cosine + top-k over its shard -> (Q, k) {score, GLOBAL index}
+  4. one all-gather of the candidates (Q*k*12 bytes per rank: KBs, so latency- not link-bound; RCCL picks
+     a direct one-hop exchange at this size, a ring would be 7 serial xGMI hops for nothing)
+  5. every rank merges world*k candidates per query with the same ordering rule
+     (higher score, then LOWER global index) -> identical to the single-GPU result, bit for bit.
+
+world_size == 1 never touches torch.distributed.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import rank as _rank
+from ._lib import MI355Error
+
+_PAD_IDX = 2 ** 62
+
+
+class _HipOps:
+    """Default compute backend: the HIP library.  (Tests inject a CPU backend to exercise the
+    collective plumbing under gloo without a GPU; the product path is always this one.)"""
+
+    @staticmethod
+    def local_topk(queries, gallery_normalized, k, idx_offset):
+        return _rank.cosine_topk(queries, gallery_normalized, k, gallery_is_normalized=True, idx_offset=idx_offset)
+
+    @staticmethod
+    def merge(cand_val, cand_idx, k):
+        return _rank.merge_topk(cand_val, cand_idx, k)
+
+    @staticmethod
+    def normalize(rows):
+        return _rank.l2_normalize_rows(rows)
+
+
+class ShardedGallery:
+    def __init__(self, local_rows: torch.Tensor, group=None, ops=None, labels: torch.Tensor | None = None):
+        self.ops = ops or _HipOps
+        self.group = group
+        dist = torch.distributed
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        if local_rows.dim() != 2:
+            raise MI355Error(f"local gallery shard must be (rows, dim), got {tuple(local_rows.shape)}")
+        self.dim = local_rows.shape[1]
+        self.device = local_rows.device
+        self.local = self.ops.normalize(local_rows.float().contiguous()) if local_rows.shape[0] else local_rows.float()
+        self.labels = labels
+        n = torch.tensor([local_rows.shape[0]], dtype=torch.int64, device=self.device)
+        if self.world > 1:
+            counts = [torch.zeros_like(n) for _ in range(self.world)]
+            dist.all_gather(counts, n, group=group)
+            counts = [int(c.item()) for c in counts]
+        else:
+            counts = [int(n.item())]
+        self.counts = counts
+        self.offsets = [0]
+        for c in counts:
+            self.offsets.append(self.offsets[-1] + c)
+        self.total_rows = self.offsets[-1]
+
+    @property
+    def offset(self) -> int:
+        return self.offsets[self.rank]
+
+    def _local_candidates(self, queries, k):
+        Q = queries.shape[0]
+        rows = self.local.shape[0]
+        kk = min(k, rows)
+        if kk > 0:
+            v, i = self.ops.local_topk(queries, self.local, kk, self.offset)
+        else:
+            v = torch.empty((Q, 0), dtype=torch.float32, device=self.device)
+            i = torch.empty((Q, 0), dtype=torch.int64, device=self.device)
+        if kk < k:  # short (or empty) shard: pad so every rank contributes exactly k slots
+            v = torch.cat([v, torch.full((Q, k - kk), float("-inf"), dtype=torch.float32, device=self.device)], 1)
+            i = torch.cat([i, torch.full((Q, k - kk), _PAD_IDX, dtype=torch.int64, device=self.device)], 1)
+        return v.contiguous(), i.contiguous()
+
+    def search(self, queries_local: torch.Tensor, k: int):
+        """Top-k of every rank's queries against the WHOLE gallery.
+
+        ``queries_local``: this rank's (Q_local, D) queries (same Q_local on every rank).
+        Returns (values, global indices) for ALL world*Q_local queries, rank-major, on every rank."""
+        if k < 1 or k > self.total_rows:
+            raise MI355Error(f"selected index k out of range: k={k}, gallery rows={self.total_rows}")
+        q = queries_local.float().contiguous()
+        if self.world == 1:
+            return self.ops.local_topk(q, self.local, k, 0)
+        dist = torch.distributed
+        Ql = q.shape[0]
+        allq = torch.empty((self.world * Ql, self.dim), dtype=torch.float32, device=self.device)
+        dist.all_gather_into_tensor(allq, q, group=self.group)
+        v, i = self._local_candidates(allq, k)
+        Q = allq.shape[0]
+        gv = torch.empty((self.world * Q, k), dtype=torch.float32, device=self.device)   # rank-major concat
+        gi = torch.empty((self.world * Q, k), dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(gv, v, group=self.group)
+        dist.all_gather_into_tensor(gi, i, group=self.group)
+        gv = gv.view(self.world, Q, k)
+        gi = gi.view(self.world, Q, k)
+        cv = gv.permute(1, 0, 2).reshape(Q, self.world * k).contiguous()
+        ci = gi.permute(1, 0, 2).reshape(Q, self.world * k).contiguous()
+        return self.ops.merge(cv, ci, k)
+
+    def my_slice(self, Q_local: int) -> slice:
+        """Rows of ``search``'s result that belong to this rank's own queries."""
+        return slice(self.rank * Q_local, (self.rank + 1) * Q_local)

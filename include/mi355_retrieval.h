@@ -165,6 +165,12 @@ int mi355_model_set_option(mi355_model_t m, const char* key, int64_t value);
 /* Accumulated per-kind kernel time (ms) and launch counts since "profile" was enabled; synchronises. */
 int mi355_model_profile_read(mi355_model_t m, double* ms_by_kind, int64_t* launches_by_kind, int n);
 
+/* Per-op profile table (plan order): average launch ms since "profile" was enabled, algorithmic bytes at
+ * batch B, kind, and a text label (labels: max_ops * label_stride chars).  Returns the number of ops
+ * (callers size the arrays with max_ops >= that; 1024 is always enough).  Developer/bench tool. */
+int mi355_model_profile_ops(mi355_model_t m, int B, int H, int W, int max_ops, double* avg_ms, double* bytes,
+                            int* kinds, char* labels, int label_stride);
+
 /* conv_input pre-stem (inference/inference.py:103-105): out = SiLU(Conv2d(3,3,3,1,1,bias=False)(x)),
  * x/out [B][3][H][W] fp32 NCHW, w [3][3][3][3] fp32 (device). */
 int mi355_conv_input_silu(const float* x, const float* w, int B, int H, int W, float* out, void* stream);
