@@ -222,45 +222,52 @@ int launch_dwconv(const bf16_t* in, const bf16_t* w, const float* bias, bf16_t* 
 }
 
 // =====================================================================================
-// SE gate.  One block per image.
+// SE gate.  One 1024-thread block (16 waves) per image: the kernel is latency-bound (tiny FLOPs, weights
+// hot in L2), so what matters is enough waves in flight and coalesced weight reads.
+// W1 [rd][C], W2T [rd][C] (transposed at pack time so both FCs read weights coalesced along C).
+// All fp32; summation orders are fixed.
 // =====================================================================================
+constexpr int SE_THREADS = 1024;
 constexpr int SE_MAX_C = 4096;
 constexpr int SE_MAX_RD = 512;
-__global__ __launch_bounds__(256) void k_se(const float* __restrict__ pool_partial, int nblk, float inv_hw,
-                                            const float* __restrict__ w1, const float* __restrict__ b1,
-                                            const float* __restrict__ w2, const float* __restrict__ b2,
-                                            float* __restrict__ gate, int C, int rd, int act1) {
+__global__ __launch_bounds__(SE_THREADS) void k_se(const float* __restrict__ pool_partial, int nblk, float inv_hw,
+                                                   const float* __restrict__ w1, const float* __restrict__ b1,
+                                                   const float* __restrict__ w2t, const float* __restrict__ b2,
+                                                   float* __restrict__ gate, int C, int rd, int act1) {
     __shared__ float s[SE_MAX_C];
     __shared__ float r[SE_MAX_RD];
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* pp = pool_partial + (size_t)b * nblk * C;
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += SE_THREADS) {
         float a = 0.f;
+#pragma unroll 8
         for (int k = 0; k < nblk; ++k) a += pp[(size_t)k * C + c];   // fixed order
         s[c] = a * inv_hw;
     }
     __syncthreads();
-    for (int j = wave; j < rd; j += 4) {
+    for (int j = wave; j < rd; j += SE_THREADS / 64) {
         const float* wr = w1 + (size_t)j * C;
         float a = 0.f;
+#pragma unroll 4
         for (int c = lane; c < C; c += 64) a += wr[c] * s[c];
         a = wave_sum(a);
         if (lane == 0) r[j] = apply_act(a + b1[j], act1);
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-        const float* wr = w2 + (size_t)c * rd;
+    for (int c = tid; c < C; c += SE_THREADS) {
         float a = b2[c];
-        for (int j = 0; j < rd; ++j) a += wr[j] * r[j];
+#pragma unroll 8
+        for (int j = 0; j < rd; ++j) a += w2t[(size_t)j * C + c] * r[j];
         gate[(size_t)b * C + c] = sigmoid_f(a);
     }
 }
 
-int launch_se(const float* pool_partial, int nblk, float inv_hw, const float* w1, const float* b1, const float* w2,
+int launch_se(const float* pool_partial, int nblk, float inv_hw, const float* w1, const float* b1, const float* w2t,
               const float* b2, float* gate, int B, int C, int rd, int act1, hipStream_t st) {
     MI355_REQUIRE(C <= SE_MAX_C && rd <= SE_MAX_RD, "se: C=%d rd=%d exceed limits", C, rd);
-    hipLaunchKernelGGL(k_se, dim3(B), dim3(256), 0, st, pool_partial, nblk, inv_hw, w1, b1, w2, b2, gate, C, rd, act1);
+    hipLaunchKernelGGL(k_se, dim3(B), dim3(SE_THREADS), 0, st, pool_partial, nblk, inv_hw, w1, b1, w2t, b2, gate, C, rd,
+                       act1);
     MI355_LAUNCH_CHECK();
     return OK;
 }

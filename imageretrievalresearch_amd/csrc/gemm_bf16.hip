@@ -17,10 +17,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int GM_BM = 128;
-constexpr int GM_BK = 32;
-constexpr int GM_LD = 40;  // LDS row stride in bf16 elements (80 B): ds_read_b128 of 16 rows is conflict-free
-
 __device__ __forceinline__ float lo_bf(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float hi_bf(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
@@ -47,12 +43,20 @@ __device__ __forceinline__ u32x4 relu6_chunk(u32x4 v) {
     return o;
 }
 
-template <int NT>
+// WM = 16-row sub-tiles per wave (block rows BM = 64*WM), NT = 16-column sub-tiles (BN = 16*NT), BK = 32 or 64.
+// LDS row stride BK+8 elements keeps ds_read_b128 of 16 consecutive rows conflict-free for both BK.
+template <int WM, int NT, int BK>
 __global__ __launch_bounds__(256) void k_gemm_bf16(const GemmArgs g, const int n_tiles, const int nwg) {
+    constexpr int BM = 64 * WM;
     constexpr int BN = NT * 16;
-    constexpr int W_ITERS = (NT * 64 + 255) / 256;
-    __shared__ __attribute__((aligned(16))) bf16_t As[2][GM_BM * GM_LD];
-    __shared__ __attribute__((aligned(16))) bf16_t Ws[2][BN * GM_LD];
+    constexpr int LD = BK + 8;
+    constexpr int KC = BK / 8;                       // 16-byte chunks per row per K-tile
+    constexpr int A_ITERS = BM * KC / 256;
+    constexpr int W_ITERS = (BN * KC + 255) / 256;
+    constexpr int CLD = BN + 8;                      // epilogue staging row stride
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    bf16_t* As = smem;                               // [2][BM*LD]
+    bf16_t* Ws = smem + 2 * BM * LD;                 // [2][BN*LD]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -67,31 +71,33 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(const GemmArgs g, const int n
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
     const int mb = logical / n_tiles, nb = logical - mb * n_tiles;
-    const int m0 = mb * GM_BM;
+    const int m0 = mb * BM;
     const int n0 = nb * BN;
     const int Npad = (g.N + 15) & ~15;
 
-    // per-thread staging coordinates
-    const int a_c = tid & 3;
-    int a_row[2];
-    const float* a_gate[2];
-    const bf16_t* a_ptr[2];
-    bool a_ok[2];
+    // per-thread staging coordinates (rows fixed across the K loop)
+    const bf16_t* a_ptr[A_ITERS];
+    const float* a_gate[A_ITERS];
+    bool a_ok[A_ITERS];
+    int a_lds[A_ITERS], a_k[A_ITERS];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        a_row[i] = (tid >> 2) + 64 * i;
-        const int m = m0 + a_row[i];
+    for (int i = 0; i < A_ITERS; ++i) {
+        const int id = tid + 256 * i;
+        const int row = id / KC, c = id % KC;
+        const int m = m0 + row;
         a_ok[i] = m < g.M;
-        a_ptr[i] = g.A + (size_t)(a_ok[i] ? m : 0) * g.lda + a_c * 8;
-        a_gate[i] = g.gate ? g.gate + (size_t)((a_ok[i] ? m : 0) / g.rows_per_img) * g.gate_ld + a_c * 8 : nullptr;
+        a_k[i] = c * 8;
+        a_lds[i] = row * LD + c * 8;
+        a_ptr[i] = g.A + (size_t)(a_ok[i] ? m : 0) * g.lda + c * 8;
+        a_gate[i] = g.gate ? g.gate + (size_t)((a_ok[i] ? m : 0) / g.rows_per_img) * g.gate_ld + c * 8 : nullptr;
     }
 
-    u32x4 ra[2], rw[W_ITERS];
+    u32x4 ra[A_ITERS], rw[W_ITERS];
     auto load_tile = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < A_ITERS; ++i) {
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (a_ok[i] && (k0 + a_c * 8) < g.K) {
+            if (a_ok[i] && (k0 + a_k[i]) < g.K) {
                 v = *reinterpret_cast<const u32x4*>(a_ptr[i] + k0);
                 if (g.gate) v = gate_chunk(v, a_gate[i] + k0, g.a_relu6);
                 else if (g.a_relu6) v = relu6_chunk(v);
@@ -101,32 +107,31 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(const GemmArgs g, const int n
 #pragma unroll
         for (int i = 0; i < W_ITERS; ++i) {
             const int id = tid + 256 * i;
-            const int row = id >> 2, c = id & 3;
+            const int row = id / KC, c = id % KC;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (row < BN && (n0 + row) < Npad)
+            if (row < BN && (n0 + row) < Npad && (k0 + c * 8) < g.ldw)
                 v = *reinterpret_cast<const u32x4*>(g.W + (size_t)(n0 + row) * g.ldw + k0 + c * 8);
             rw[i] = v;
         }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            *reinterpret_cast<u32x4*>(&As[buf][a_row[i] * GM_LD + a_c * 8]) = ra[i];
+        for (int i = 0; i < A_ITERS; ++i) *reinterpret_cast<u32x4*>(&As[buf * BM * LD + a_lds[i]]) = ra[i];
 #pragma unroll
         for (int i = 0; i < W_ITERS; ++i) {
             const int id = tid + 256 * i;
-            const int row = id >> 2, c = id & 3;
-            if (row < BN) *reinterpret_cast<u32x4*>(&Ws[buf][row * GM_LD + c * 8]) = rw[i];
+            const int row = id / KC, c = id % KC;
+            if (row < BN) *reinterpret_cast<u32x4*>(&Ws[buf * BN * LD + row * LD + c * 8]) = rw[i];
         }
     };
 
-    f32x4 acc[NT][2];
+    f32x4 acc[NT][WM];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < WM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nt = (g.K + GM_BK - 1) / GM_BK;
+    const int nt = (g.K + BK - 1) / BK;
     load_tile(0);
     store_tile(0);
     __syncthreads();
@@ -135,26 +140,61 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(const GemmArgs g, const int n
     const int fk = (lane >> 4) * 8;    // fragment k offset
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nt) load_tile((t + 1) * GM_BK);
-        bf16x8 af[2];
+        if (t + 1 < nt) load_tile((t + 1) * BK);
+        const bf16_t* as = As + buf * BM * LD;
+        const bf16_t* ws = Ws + buf * BN * LD;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-            af[mi] = *reinterpret_cast<const bf16x8*>(&As[buf][(wave * 32 + mi * 16 + fr) * GM_LD + fk]);
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8 af[WM];
 #pragma unroll
-        for (int ni = 0; ni < NT; ++ni) {
-            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(&Ws[buf][(ni * 16 + fr) * GM_LD + fk]);
+            for (int mi = 0; mi < WM; ++mi)
+                af[mi] = *reinterpret_cast<const bf16x8*>(&as[(wave * 16 * WM + mi * 16 + fr) * LD + ks * 32 + fk]);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[mi], acc[ni][mi], 0, 0, 0);
+            for (int ni = 0; ni < NT; ++ni) {
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(&ws[(ni * 16 + fr) * LD + ks * 32 + fk]);
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[mi], acc[ni][mi], 0, 0, 0);
+            }
         }
         if (t + 1 < nt) store_tile(buf ^ 1);
         __syncthreads();
     }
 
     // epilogue: D[row = n][col = m]; lane holds n = nbase + (lane>>4)*4 + r (r = 0..3), m = lane & 15.
+    const bool staged = (!g.out_f32) && (g.res == nullptr);
+    if (staged) {
+        // bf16 tile -> LDS -> 16-byte row-contiguous stores (the stage buffers are free after the last barrier)
+        bf16_t* Cs = smem;   // [BM][CLD]
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int m = m0 + wave * 32 + mi * 16 + fr;
+        for (int mi = 0; mi < WM; ++mi) {
+            const int ml = wave * 16 * WM + mi * 16 + fr;
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                const int nl = ni * 16 + (lane >> 4) * 4;
+                const int n = n0 + nl;
+                f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                if (n < Npad) b = *reinterpret_cast<const f32x4*>(g.bias + n);
+                u32x2 o;
+                o.x = pack2bf(apply_act(acc[ni][mi].x + b.x, g.act), apply_act(acc[ni][mi].y + b.y, g.act));
+                o.y = pack2bf(apply_act(acc[ni][mi].z + b.z, g.act), apply_act(acc[ni][mi].w + b.w, g.act));
+                *reinterpret_cast<u32x2*>(&Cs[ml * CLD + nl]) = o;
+            }
+        }
+        __syncthreads();
+        constexpr int CPR = BN / 8;   // 16-byte chunks per tile row
+        for (int id = tid; id < BM * CPR; id += 256) {
+            const int row = id / CPR, c = id - row * CPR;
+            const int m = m0 + row, n = n0 + c * 8;
+            if (m < g.M && n < g.N)   // N is a multiple of 8 for bf16 outputs
+                *reinterpret_cast<u32x4*>((bf16_t*)g.out + (size_t)m * g.ldo + n) =
+                    *reinterpret_cast<const u32x4*>(&Cs[row * CLD + c * 8]);
+        }
+        return;
+    }
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi) {
+        const int m = m0 + wave * 16 * WM + mi * 16 + fr;
         if (m >= g.M) continue;
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
@@ -195,9 +235,11 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(const GemmArgs g, const int n
     }
 }
 
-// Pick BN = 16*NT: minimise padded columns, prefer fewer/larger tiles (fewer A-panel re-reads).
+// Tile selection.  BN = 16*NT minimising padded columns (prefer fewer, larger tiles: fewer A-panel re-reads);
+// BM = 64 when a 128-row tiling would leave the 256 CUs with < 4 blocks each (late 14x14 / 7x7 layers are
+// latency-bound: more, smaller blocks overlap their load latency); BK = 64 once K >= 64.
 static int pick_nt(int N) {
-    static const int opts[] = {2, 3, 4, 5, 6, 8, 9, 12};
+    static const int opts[] = {2, 3, 4, 6, 8, 9, 12};
     int best = 2;
     double best_cost = 1e30;
     for (int nt : opts) {
@@ -209,34 +251,52 @@ static int pick_nt(int N) {
     return best;
 }
 
-template <int NT>
-static int launch_nt(const GemmArgs& a, hipStream_t st) {
-    const int bn = NT * 16;
-    const int n_tiles = cdiv(a.N, bn);
-    const int m_tiles = cdiv(a.M, GM_BM);
+template <int WM, int NT, int BK>
+static int launch_cfg(const GemmArgs& a, hipStream_t st) {
+    constexpr int BM = 64 * WM, BN = NT * 16, LD = BK + 8;
+    constexpr size_t stage = (size_t)2 * (BM + BN) * LD * 2, ctile = (size_t)BM * (BN + 8) * 2;
+    constexpr size_t lds = stage > ctile ? stage : ctile;
+    static bool attr_done = false;
+    if (!attr_done) {
+        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_bf16<WM, NT, BK>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const int n_tiles = cdiv(a.N, BN);
+    const int m_tiles = cdiv(a.M, BM);
     const long nwg = (long)n_tiles * m_tiles;
     MI355_REQUIRE(nwg < (1l << 31), "gemm: grid too large");
-    hipLaunchKernelGGL((k_gemm_bf16<NT>), dim3((unsigned)nwg), dim3(256), 0, st, a, n_tiles, (int)nwg);
+    hipLaunchKernelGGL((k_gemm_bf16<WM, NT, BK>), dim3((unsigned)nwg), dim3(256), lds, st, a, n_tiles, (int)nwg);
     MI355_LAUNCH_CHECK();
     return OK;
+}
+
+template <int WM, int BK>
+static int launch_nt(const GemmArgs& a, int nt, hipStream_t st) {
+    switch (nt) {
+        case 2: return launch_cfg<WM, 2, BK>(a, st);
+        case 3: return launch_cfg<WM, 3, BK>(a, st);
+        case 4: return launch_cfg<WM, 4, BK>(a, st);
+        case 6: return launch_cfg<WM, 6, BK>(a, st);
+        case 8: return launch_cfg<WM, 8, BK>(a, st);
+        case 9: return launch_cfg<WM, 9, BK>(a, st);
+        default: return launch_cfg<WM, 12, BK>(a, st);
+    }
 }
 
 int launch_gemm_bf16(const GemmArgs& a, hipStream_t st) {
     MI355_REQUIRE(a.M >= 1 && a.N >= 1 && a.K >= 1, "gemm: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
     MI355_REQUIRE(a.K % 8 == 0 && a.lda % 8 == 0 && a.ldw % 32 == 0, "gemm: K=%d lda=%d ldw=%d alignment", a.K, a.lda,
                   a.ldw);
-    MI355_REQUIRE(a.out_f32 || a.ldo % 4 == 0, "gemm: bf16 output stride %d must be a multiple of 4", a.ldo);
+    MI355_REQUIRE(a.out_f32 || (a.ldo % 8 == 0 && a.N % 8 == 0), "gemm: bf16 output needs N, ldo multiples of 8 (N=%d ldo=%d)",
+                  a.N, a.ldo);
     MI355_REQUIRE(!a.res || a.ldr % 4 == 0, "gemm: residual stride %d must be a multiple of 4", a.ldr);
-    switch (pick_nt(a.N)) {
-        case 2: return launch_nt<2>(a, st);
-        case 3: return launch_nt<3>(a, st);
-        case 4: return launch_nt<4>(a, st);
-        case 5: return launch_nt<5>(a, st);
-        case 6: return launch_nt<6>(a, st);
-        case 8: return launch_nt<8>(a, st);
-        case 9: return launch_nt<9>(a, st);
-        default: return launch_nt<12>(a, st);
-    }
+    // Measured on MI355X (profiles/r01_effnet_per_op_*.txt): the 64-row / BK=64 variants lose to 128 x BN x 32
+    // on every EfficientNet layer (each wave re-reads the whole W tile from LDS, so halving the rows per wave
+    // makes the block LDS-bound); they stay instantiated for tiny-M problems (classifier, M = batch).
+    const int nt = pick_nt(a.N);
+    if (a.M <= 64) return a.K >= 64 ? launch_nt<1, 64>(a, nt, st) : launch_nt<1, 32>(a, nt, st);
+    return launch_nt<2, 32>(a, nt, st);
 }
 
 }  // namespace mi355

@@ -200,7 +200,7 @@ static int pack_se(Packer& pk, Op& op) {
         B1[j] = b1->data[j] * scale[j] + shift[j];
     }
     for (int c = 0; c < C; ++c) {
-        for (int j = 0; j < rd; ++j) W2[(size_t)c * rd + j] = w2->data[(size_t)c * rd + j];
+        for (int j = 0; j < rd; ++j) W2[(size_t)j * Cp + c] = w2->data[(size_t)c * rd + j];   // transposed [rd][Cp]
         B2[c] = b2->data[c];
     }
     return OK;

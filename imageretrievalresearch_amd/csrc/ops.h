@@ -37,7 +37,7 @@ int launch_dwconv(const bf16_t* in, const bf16_t* w, const float* bias, bf16_t* 
                   int H, int W, int C, int k, int stride, int act, hipStream_t st);
 
 // Squeeze-excite gate: s = (sum over nblk partials) / hw ; r = act1(W1 s + b1) ; gate = sigmoid(W2 r + b2).
-// W1 [rd][C] fp32, W2 [C][rd] fp32.  gate out [B][C] fp32.
+// W1 [rd][C] fp32, W2T [rd][C] fp32 (transposed).  gate out [B][C] fp32.
 int launch_se(const float* pool_partial, int nblk, float inv_hw, const float* w1, const float* b1, const float* w2,
               const float* b2, float* gate, int B, int C, int rd, int act1, hipStream_t st);
 

@@ -346,7 +346,7 @@ class ConvInput(nn.Sequential):
     def forward(self, x):
         require_cuda(x, "conv_input input")
         x = x.detach().float().contiguous()
-        w = self[0].weight.detach().float().contiguous()
+        w = self[0].weight.detach().to(x.device, torch.float32).contiguous()   # weight may still live on the CPU
         out = torch.empty_like(x)
         B, _, H, W = x.shape
         if B:
