@@ -150,13 +150,13 @@ def main():
         prof = model.profile_read()
         model.set_option("profile", 0)
         tr = model.traffic(a.batch)
-        fam = max(("gemm", "dw", "stem", "se", "attn", "ln", "other"), key=lambda k: prof[k]["ms"])
+        fam = max(("gemm", "dw", "fused", "stem", "se", "attn", "ln", "other"), key=lambda k: prof[k]["ms"])
         launches = max(1, prof[fam]["launches"])
         avg_ms = prof[fam]["ms"] / launches
         bytes_per_launch = tr["bytes_by_kind"][fam] / (launches / 3)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         kernel_names = {"gemm": "k_gemm_bf16 (1x1 conv)", "dw": "k_dwconv (depthwise + SE squeeze)",
-                        "stem": "k_stem", "se": "k_se", "attn": "k_win_attn", "ln": "k_layernorm", "other": "other"}
+                        "fused": "k_fused_late (1x1 expand + depthwise + SE squeeze, expanded tensor in LDS)", "stem": "k_stem", "se": "k_se", "attn": "k_win_attn", "ln": "k_layernorm", "other": "other"}
         roofline = {"bound": "hbm", "kernel": kernel_names[fam], "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,

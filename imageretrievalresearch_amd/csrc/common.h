@@ -46,8 +46,12 @@ __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
     return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// sigmoid/SiLU on the transcendental pipe: exp2 + rcp (1 ulp each), no IEEE division sequence.  Every result is
+// rounded to bf16 (8 bits) right after, so the ~1e-7 relative difference to expf()/div is invisible.
+__device__ __forceinline__ float sigmoid_f(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 
 // activation codes shared by the conv / GEMM epilogues
 enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_RELU6 = 3, ACT_GELU = 4, ACT_SIGMOID = 5 };

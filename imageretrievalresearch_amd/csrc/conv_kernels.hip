@@ -132,6 +132,9 @@ __global__ __launch_bounds__(256) void k_dwconv(const bf16_t* __restrict__ in, c
             for (int j = 0; j < 8; ++j) acc[p][j] = bs[j];
 
         const bf16_t* inb = in + (size_t)b * H * W * C + c0;
+        // NOTE (measured, profiles/r01_effnet_per_op_*.txt): a branch-free "interior" fast path and a rolled ky
+        // loop were both SLOWER here (0.25 -> 0.31 ms on the 56x56 C192 layer): this kernel is bound by load
+        // latency, and the fully unrolled form lets the compiler issue every tap's load up front.
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky) {
             const int iy = oy * S - PAD + ky;

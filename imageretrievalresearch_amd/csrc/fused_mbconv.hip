@@ -1,0 +1,280 @@
+// Fused MBConv front half for the late stages: 1x1 expand (MFMA) -> bias+act -> depthwise kxk -> bias+act
+// -> SE squeeze, with the expanded tensor living ONLY in LDS.  gfx950 only.
+//
+// Why: in the layer-granular traffic model the expanded activation (6x the block width) is written by the
+// expand conv and read back by the depthwise conv — 46 % of all HBM bytes of EfficientNet-B3.  MI355X has
+// 160 KB of LDS per CU, enough to hold a whole 14x14 or 7x7 image of X (all input channels) plus a 128..512
+// channel slab of the expanded tensor, so one workgroup per image can run expand -> depthwise back to back:
+// HBM sees X once and the depthwise output once.  Whole-image tiles need no halo recompute, and the SE
+// squeeze of a channel is complete inside one workgroup (no partial sums, fixed summation order).
+//
+// Workgroup = 8 waves.  Per channel slab (MC = 128*NIW channels):
+//   phase 1  each wave owns 16*NIW output channels and sweeps all pixels: A fragments (pixels) come from the
+//            LDS image of X, W fragments straight from L2 in MFMA layout (each W element is read once per
+//            workgroup), D = W x X^T so a lane holds 4 consecutive channels of one pixel -> 8-byte LDS writes
+//   phase 2  thread = 8 channels x PX output pixels of one row, taps read from the LDS slab (zero padding by
+//            bounds checks), result streamed to HBM as 16-byte NHWC vectors; per-channel sums reduced through
+//            LDS in thread order.
+#include "ops.h"
+
+namespace mi355 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void fl_unpack8(u32x4 v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+
+constexpr int FL_THREADS = 512;
+
+template <int KS, int S, int NIW, int PX>
+__global__ __launch_bounds__(FL_THREADS) void k_fused_late(const FusedArgs a) {
+    constexpr int MC = 128 * NIW;                               // channels per slab
+    constexpr int MTP = NIW == 1 ? 13 : (NIW == 2 ? 7 : 4);     // 16-pixel sub-tiles per GEMM pass
+    constexpr int PAD = KS / 2;
+    constexpr int IW = (PX - 1) * S + KS;
+    constexpr int CGC = MC / 8;                                 // channel groups per slab
+    extern __shared__ __attribute__((aligned(16))) bf16_t fsm[];
+    const int P = a.H * a.W;
+    const int MT = (P + 15) >> 4;
+    const int XLD = a.Kp + 8;
+    constexpr int ELD = MC + 8;
+    // E slab image: rows of (W + 2*PAD) pixels with zero columns left and right, so the depthwise taps need no
+    // x bounds checks (the branchy checked form costs ~8x the FMAs it feeds); EP pixels + IW slack for the
+    // discarded lanes of a partial strip.
+    const int EW = a.W + 2 * PAD;
+    const int EP = a.H * EW + IW;
+    bf16_t* Xs = fsm;                        // [MT*16][XLD]
+    bf16_t* Es = fsm + (size_t)MT * 16 * XLD;  // [EP][ELD]
+    float* red = reinterpret_cast<float*>(Es + (size_t)((EP + 7) & ~7) * ELD);   // [FL_THREADS][8]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int nchunks = (a.mid + MC - 1) / MC;
+    const int cpb = (nchunks + gridDim.x - 1) / gridDim.x;
+    const int chunk0 = blockIdx.x * cpb;
+    const int chunk1 = min(nchunks, chunk0 + cpb);
+
+    // ---- phase 0: X[b] -> LDS (zero fill for k >= Cin and rows >= P)
+    {
+        const int kc = a.Kp >> 3;
+        const bf16_t* xb = a.X + (size_t)b * P * a.Cin;
+        for (int id = tid; id < MT * 16 * kc; id += FL_THREADS) {
+            const int row = id / kc, c = id - row * kc;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (row < P && c * 8 < a.Cin) v = *reinterpret_cast<const u32x4*>(xb + (size_t)row * a.Cin + c * 8);
+            *reinterpret_cast<u32x4*>(&Xs[row * XLD + c * 8]) = v;
+        }
+        // zero the whole E image once: the pad columns are never written again
+        for (int id = tid; id < EP * (ELD / 8); id += FL_THREADS)
+            *reinterpret_cast<u32x4*>(&Es[(size_t)id * 8]) = (u32x4){0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
+
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    const int midp = (a.mid + 15) & ~15;
+    const int strips = (a.Wo + PX - 1) / PX;
+    const int nitems = CGC * strips * a.Ho;
+
+    for (int chunk = chunk0; chunk < chunk1; ++chunk) {
+        const int cbase = chunk * MC;
+        // ---- phase 1: E slab = act(X W^T + b) -> Es (bf16)
+        if (!(a.debug_skip & 1))
+        for (int mb = 0; mb < MT; mb += MTP) {
+            f32x4 acc[NIW][MTP];
+#pragma unroll
+            for (int j = 0; j < NIW; ++j)
+#pragma unroll
+                for (int m = 0; m < MTP; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const bf16_t* wrow[NIW];
+            bool wok[NIW];
+#pragma unroll
+            for (int j = 0; j < NIW; ++j) {
+                const int n = cbase + (wave * NIW + j) * 16 + fr;
+                wok[j] = n < midp;
+                wrow[j] = a.We + (size_t)(wok[j] ? n : 0) * a.Kp + fk;
+            }
+            u32x4 wnext[NIW];
+#pragma unroll
+            for (int j = 0; j < NIW; ++j) wnext[j] = wok[j] ? *reinterpret_cast<const u32x4*>(wrow[j]) : (u32x4){0u, 0u, 0u, 0u};
+            for (int ks = 0; ks < a.Kp; ks += 32) {
+                bf16x8 wf[NIW];
+#pragma unroll
+                for (int j = 0; j < NIW; ++j) {
+                    wf[j] = *reinterpret_cast<bf16x8*>(&wnext[j]);
+                    // prefetch the next k-step's W fragment while this step's MFMAs run
+                    if (ks + 32 < a.Kp && wok[j]) wnext[j] = *reinterpret_cast<const u32x4*>(wrow[j] + ks + 32);
+                }
+#pragma unroll
+                for (int m = 0; m < MTP; ++m) {
+                    if (mb + m < MT) {
+                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(&Xs[((mb + m) * 16 + fr) * XLD + ks + fk]);
+#pragma unroll
+                        for (int j = 0; j < NIW; ++j)
+                            acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af, acc[j][m], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < MTP; ++m) {
+                const int p = (mb + m) * 16 + fr;          // this lane's pixel
+                if (mb + m < MT && p < P) {
+                    const int y = p / a.W;
+                    const int erow = y * EW + (p - y * a.W) + PAD;
+#pragma unroll
+                    for (int j = 0; j < NIW; ++j) {
+                        const int nl = (wave * NIW + j) * 16 + (lane >> 4) * 4;   // channel within the slab
+                        const int n = cbase + nl;
+                        f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+                        if (n < midp) bb = *reinterpret_cast<const f32x4*>(a.be + n);
+                        u32x2 o;
+                        o.x = pack2bf(apply_act(acc[j][m].x + bb.x, a.act_e), apply_act(acc[j][m].y + bb.y, a.act_e));
+                        o.y = pack2bf(apply_act(acc[j][m].z + bb.z, a.act_e), apply_act(acc[j][m].w + bb.w, a.act_e));
+                        *reinterpret_cast<u32x2*>(&Es[(size_t)erow * ELD + nl]) = o;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 2: depthwise from the LDS slab
+        float psum[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) psum[j] = 0.f;
+        const int my_cg = tid % CGC;                 // FL_THREADS % CGC == 0: a thread keeps one channel group
+        const int c0 = cbase + my_cg * 8;
+        const bool cok = c0 < a.mid;
+        if (!(a.debug_skip & 2))
+        for (int item = tid; item < nitems; item += FL_THREADS) {
+            const int rest = item / CGC;
+            const int sx = rest % strips, oy = rest / strips;
+            const int ox0 = sx * PX;
+            if (!cok) continue;
+            float acc[PX][8];
+            {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bd + c0);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.bd + c0 + 4);
+#pragma unroll
+                for (int p = 0; p < PX; ++p) {
+                    acc[p][0] = b0.x; acc[p][1] = b0.y; acc[p][2] = b0.z; acc[p][3] = b0.w;
+                    acc[p][4] = b1.x; acc[p][5] = b1.y; acc[p][6] = b1.z; acc[p][7] = b1.w;
+                }
+            }
+#pragma unroll 1
+            for (int ky = 0; ky < KS; ++ky) {
+                const int iy = oy * S - PAD + ky;
+                if (iy < 0 || iy >= a.H) continue;
+                float wk[KS][8];
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx)
+                    fl_unpack8(*reinterpret_cast<const u32x4*>(a.Wd + (size_t)(ky * KS + kx) * a.mid + c0), wk[kx]);
+                const bf16_t* erow = Es + (size_t)(iy * EW + ox0 * S) * ELD + my_cg * 8;   // padded x: no checks
+#pragma unroll
+                for (int i = 0; i < IW; ++i) {
+                    float v[8];
+                    fl_unpack8(*reinterpret_cast<const u32x4*>(erow + (size_t)i * ELD), v);
+#pragma unroll
+                    for (int p = 0; p < PX; ++p) {
+                        const int kx = i - p * S;
+                        if (kx >= 0 && kx < KS) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[p][j] += wk[kx][j] * v[j];
+                        }
+                    }
+                }
+            }
+            bf16_t* o = a.D + (((size_t)b * a.Ho + oy) * a.Wo + ox0) * a.mid + c0;
+#pragma unroll
+            for (int p = 0; p < PX; ++p) {
+                if (ox0 + p < a.Wo) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        acc[p][j] = apply_act(acc[p][j], a.act_d);
+                        psum[j] += acc[p][j];
+                    }
+                    u32x4 ov;
+                    ov.x = pack2bf(acc[p][0], acc[p][1]); ov.y = pack2bf(acc[p][2], acc[p][3]);
+                    ov.z = pack2bf(acc[p][4], acc[p][5]); ov.w = pack2bf(acc[p][6], acc[p][7]);
+                    *reinterpret_cast<u32x4*>(o + (size_t)p * a.mid) = ov;
+                }
+            }
+        }
+        if (a.pool != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[tid * 8 + j] = psum[j];
+            __syncthreads();
+            if (tid < CGC && cbase + tid * 8 < a.mid) {
+                float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int u = tid; u < FL_THREADS; u += CGC) {   // same channel group, thread order
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s[j] += red[u * 8 + j];
+                }
+                float* pp = a.pool + (size_t)b * a.mid + cbase + tid * 8;
+                *reinterpret_cast<f32x4*>(pp) = (f32x4){s[0], s[1], s[2], s[3]};
+                *reinterpret_cast<f32x4*>(pp + 4) = (f32x4){s[4], s[5], s[6], s[7]};
+            }
+        }
+        __syncthreads();   // Es / red are rewritten by the next slab
+    }
+}
+
+static size_t fused_lds_bytes(int H, int W, int Kp, int MC, int k, int stride) {
+    const int P = H * W, MT = (P + 15) / 16, pad = k / 2;
+    const int px = ((W + 2 * pad - k) / stride + 1) % 7 == 0 ? 7 : 4;
+    const int iw = (px - 1) * stride + k;
+    const int EP = H * (W + 2 * pad) + iw;
+    return (size_t)MT * 16 * (Kp + 8) * 2 + (size_t)((EP + 7) & ~7) * (MC + 8) * 2 + FL_THREADS * 8 * 4;
+}
+
+bool fused_late_supported(int H, int W, int Cin, int mid, int k, int stride) {
+    if (H * W > 208 || Cin % 8 || mid % 8) return false;
+    if (!((k == 3 || k == 5) && (stride == 1 || stride == 2))) return false;
+    const int P = H * W, MT = (P + 15) / 16;
+    const int niw = P <= 64 ? 4 : (P <= 112 ? 2 : 1);
+    const int Kp = (Cin + 31) & ~31;
+    return fused_lds_bytes(H, W, Kp, 128 * niw, k, stride) <= 160 * 1024;
+}
+
+template <int KS, int S, int NIW, int PX>
+static int launch_fl(const FusedArgs& a, int B, hipStream_t st) {
+    constexpr int MC = 128 * NIW;
+    const size_t lds = fused_lds_bytes(a.H, a.W, a.Kp, MC, KS, S);
+    static bool attr_done = false;
+    if (!attr_done) {
+        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_fused_late<KS, S, NIW, PX>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    const int nchunks = cdiv(a.mid, MC);
+    int G = 256 / (B > 0 ? B : 1);
+    if (G < 1) G = 1;
+    if (G > nchunks) G = nchunks;
+    hipLaunchKernelGGL((k_fused_late<KS, S, NIW, PX>), dim3(G, B), dim3(FL_THREADS), lds, st, a);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
+template <int KS, int S>
+static int launch_fl_ks(const FusedArgs& a, int B, hipStream_t st) {
+    const int P = a.H * a.W;
+    const bool px7 = (a.Wo % 7 == 0);
+    if (P <= 64) return px7 ? launch_fl<KS, S, 4, 7>(a, B, st) : launch_fl<KS, S, 4, 4>(a, B, st);
+    if (P <= 112) return px7 ? launch_fl<KS, S, 2, 7>(a, B, st) : launch_fl<KS, S, 2, 4>(a, B, st);
+    return px7 ? launch_fl<KS, S, 1, 7>(a, B, st) : launch_fl<KS, S, 1, 4>(a, B, st);
+}
+
+int launch_fused_late(const FusedArgs& a, int B, int k, int stride, hipStream_t st) {
+    MI355_REQUIRE(fused_late_supported(a.H, a.W, a.Cin, a.mid, k, stride), "fused_late: unsupported shape");
+    if (k == 3 && stride == 1) return launch_fl_ks<3, 1>(a, B, st);
+    if (k == 3 && stride == 2) return launch_fl_ks<3, 2>(a, B, st);
+    if (k == 5 && stride == 1) return launch_fl_ks<5, 1>(a, B, st);
+    return launch_fl_ks<5, 2>(a, B, st);
+}
+
+}  // namespace mi355

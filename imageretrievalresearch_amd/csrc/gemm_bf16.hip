@@ -149,12 +149,21 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(const GemmArgs g, const int n
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi)
                 af[mi] = *reinterpret_cast<const bf16x8*>(&as[(wave * 16 * WM + mi * 16 + fr) * LD + ks * 32 + fk]);
+            // W fragments are fetched WG at a time so several ds_read_b128 are in flight behind the MFMAs
+            // (hipcc otherwise pairs them and exposes the ~100-cycle LDS latency six times per k-step)
+            constexpr int WG = NT % 4 == 0 ? 4 : (NT % 3 == 0 ? 3 : 2);
 #pragma unroll
-            for (int ni = 0; ni < NT; ++ni) {
-                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(&ws[(ni * 16 + fr) * LD + ks * 32 + fk]);
+            for (int n0i = 0; n0i < NT; n0i += WG) {
+                bf16x8 wf[WG];
 #pragma unroll
-                for (int mi = 0; mi < WM; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[mi], acc[ni][mi], 0, 0, 0);
+                for (int q = 0; q < WG; ++q)
+                    wf[q] = *reinterpret_cast<const bf16x8*>(&ws[((n0i + q) * 16 + fr) * LD + ks * 32 + fk]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < WG; ++q)
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi)
+                        acc[n0i + q][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[q], af[mi], acc[n0i + q][mi], 0, 0, 0);
             }
         }
         if (t + 1 < nt) store_tile(buf ^ 1);

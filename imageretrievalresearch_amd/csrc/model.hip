@@ -38,7 +38,7 @@ struct TapBuf {
     int B = 0, h = 0, w = 0, c = 0, c_real = 0;
 };
 
-enum { PK_STEM = 0, PK_GEMM, PK_DW, PK_SE, PK_OTHER, PK_ATTN, PK_LN, PK_COUNT };
+enum { PK_STEM = 0, PK_GEMM, PK_DW, PK_SE, PK_OTHER, PK_ATTN, PK_LN, PK_FUSED, PK_COUNT };
 
 }  // namespace mi355
 
@@ -54,11 +54,15 @@ struct mi355_model {
     size_t arena_bytes = 0;
     SlotState slots[SLOT_COUNT];
     int microbatch = 0;
+    bool fuse = true;           // fused expand+depthwise for whole-image tiles (option "fuse")
+    int fuse_debug = 0;
+    int pool_nblk = 0;          // squeeze partials per image produced by the last depthwise stage
     bool taps = false;
     std::map<std::string, TapBuf> tapbufs;
     // per-kind profiling with hipEvents (option "profile")
     bool profile = false;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;  // (op index, events)
+    std::vector<char> prof_fused;   // op index -> executed as a fused expand+depthwise pair
     std::vector<double> prof_op_ms;
     std::vector<long> prof_op_n;
     double prof_ms[PK_COUNT] = {0};
@@ -336,6 +340,7 @@ static int exec_op(ExecCtx& cx, const Op& op) {
             return launch_gemm_bf16(a, cx.st);
         }
         case OP_DW:
+            m->pool_nblk = dw_pool_blocks(conv_out(S[op.in].h, op.k, op.stride), conv_out(S[op.in].w, op.k, op.stride), op.cin);
             return launch_dwconv((const bf16_t*)cx.slot_ptr(op.in), (const bf16_t*)cx.w(op.w_off),
                                  (const float*)cx.w(op.b_off), (bf16_t*)cx.slot_ptr(op.out),
                                  op.pool ? (float*)cx.slot_ptr(SLOT_POOLPART) : nullptr, cx.nb, S[op.in].h, S[op.in].w,
@@ -343,7 +348,7 @@ static int exec_op(ExecCtx& cx, const Op& op) {
         case OP_SE: {
             // the squeeze partials were produced by the preceding depthwise conv into SLOT_D's geometry
             const int ho = S[SLOT_D].h, wo = S[SLOT_D].w;
-            return launch_se((const float*)cx.slot_ptr(SLOT_POOLPART), dw_pool_blocks(ho, wo, op.cin),
+            return launch_se((const float*)cx.slot_ptr(SLOT_POOLPART), m->pool_nblk,
                              1.0f / (float)(ho * wo), (const float*)cx.w(op.w_off), (const float*)cx.w(op.b_off),
                              (const float*)cx.w(op.w2_off), (const float*)cx.w(op.b2_off),
                              (float*)cx.slot_ptr(SLOT_GATE), cx.nb, op.cin, op.rd, op.se_act, cx.st);
@@ -353,14 +358,47 @@ static int exec_op(ExecCtx& cx, const Op& op) {
     }
 }
 
+// expand GEMM (-> SLOT_E) immediately followed by the depthwise conv that consumes it, on a whole-image tile
+static bool can_fuse(const mi355_model* m, size_t i, int h, int w) {
+    if (!m->fuse || i + 1 >= m->def.ops.size()) return false;
+    const Op& g = m->def.ops[i];
+    const Op& d = m->def.ops[i + 1];
+    if (g.kind != OP_GEMM || d.kind != OP_DW || g.out != SLOT_E || d.in != SLOT_E) return false;
+    if (g.use_gate || g.res != SLOT_NONE || g.a_relu6 || !g.tap.empty()) return false;
+    return fused_late_supported(h, w, g.cin, g.cout, d.k, d.stride);
+}
+
+static int exec_fused(ExecCtx& cx, const Op& g, const Op& d) {
+    mi355_model* m = cx.m;
+    SlotState* S = m->slots;
+    FusedArgs a{};
+    a.X = (const bf16_t*)cx.slot_ptr(g.in);
+    a.We = (const bf16_t*)cx.w(g.w_off); a.be = (const float*)cx.w(g.b_off);
+    a.Wd = (const bf16_t*)cx.w(d.w_off); a.bd = (const float*)cx.w(d.b_off);
+    a.D = (bf16_t*)cx.slot_ptr(d.out);
+    a.pool = d.pool ? (float*)cx.slot_ptr(SLOT_POOLPART) : nullptr;
+    a.H = S[g.in].h; a.W = S[g.in].w; a.Cin = g.cin; a.Kp = (g.cin + 31) & ~31; a.mid = g.cout;
+    a.Ho = S[d.out].h; a.Wo = S[d.out].w; a.act_e = g.act; a.act_d = d.act;
+    a.debug_skip = m->fuse_debug;
+    m->pool_nblk = 1;
+    return launch_fused_late(a, cx.nb, d.k, d.stride, cx.st);
+}
+
 static int run_backbone(ExecCtx& cx) {
     mi355_model* m = cx.m;
     // NOTE: slot dims for DW/SE depend on walk order; plan_slots() left the LAST writer's dims in each
     // slot, so re-derive dims incrementally while executing.
     SlotState* S = m->slots;
-    int op_index = -1;
-    for (const Op& op : m->def.ops) {
-        ++op_index;
+    for (size_t oi = 0; oi < m->def.ops.size(); ++oi) {
+        const Op& op = m->def.ops[oi];
+        const int op_index = (int)oi;
+        const bool fused = can_fuse(m, oi, S[op.in == SLOT_NONE ? 0 : op.in].h, S[op.in == SLOT_NONE ? 0 : op.in].w);
+        if (fused) {   // dims of the (virtual) expand output and of the depthwise output
+            const Op& d = m->def.ops[oi + 1];
+            S[op.out].h = S[op.in].h; S[op.out].w = S[op.in].w; S[op.out].c = op.cout;
+            S[d.out].h = conv_out(S[op.in].h, d.k, d.stride); S[d.out].w = conv_out(S[op.in].w, d.k, d.stride);
+            S[d.out].c = d.cout;
+        } else
         switch (op.kind) {
             case OP_STEM: S[op.out].h = conv_out(cx.H, 3, 2); S[op.out].w = conv_out(cx.W, 3, 2); S[op.out].c = op.cout; break;
             case OP_GEMM: S[op.out].h = S[op.in].h; S[op.out].w = S[op.in].w; S[op.out].c = op.cout; break;
@@ -378,13 +416,18 @@ static int run_backbone(ExecCtx& cx) {
             MI355_CHECK_HIP(hipEventCreate(&e1));
             MI355_CHECK_HIP(hipEventRecord(e0, cx.st));
         }
-        if (int e = exec_op(cx, op)) return e;
+        if (fused) {
+            if (int e = exec_fused(cx, op, m->def.ops[oi + 1])) return e;
+        } else if (int e = exec_op(cx, op)) return e;
         if (m->profile) {
             MI355_CHECK_HIP(hipEventRecord(e1, cx.st));
             m->prof_events.push_back({op_index, {e0, e1}});
+            if (m->prof_fused.size() < m->def.ops.size()) m->prof_fused.resize(m->def.ops.size(), 0);
+            m->prof_fused[op_index] = fused ? 1 : 0;
         }
         if (m->taps && !op.tap.empty())
             if (int e = record_tap(cx, op)) return e;
+        if (fused) ++oi;   // the depthwise op was executed together with the expand
     }
     return OK;
 }
@@ -586,6 +629,8 @@ int mi355_model_set_option(mi355_model_t m, const char* key, int64_t value) {
     MI355_REQUIRE(m && key, "set_option: null argument");
     const std::string k = key;
     if (k == "microbatch") m->microbatch = (int)value;
+    else if (k == "fuse") m->fuse = value != 0;
+    else if (k == "fuse_debug") m->fuse_debug = (int)value;
     else if (k == "profile") {
         m->profile = value != 0;
         for (int i = 0; i < PK_COUNT; ++i) { m->prof_ms[i] = 0; m->prof_launches[i] = 0; }
@@ -604,7 +649,9 @@ int mi355_model_profile_read(mi355_model_t m, double* ms_by_kind, int64_t* launc
         MI355_CHECK_HIP(hipEventSynchronize(pe.second.second));
         float ms = 0.f;
         MI355_CHECK_HIP(hipEventElapsedTime(&ms, pe.second.first, pe.second.second));
-        const int kd = prof_kind(m->def.ops[pe.first]);
+        int kd = prof_kind(m->def.ops[pe.first]);
+        if (m->fuse && m->def.ops[pe.first].kind == OP_GEMM && m->def.ops[pe.first].out == SLOT_E &&
+            (size_t)pe.first < m->prof_fused.size() && m->prof_fused[pe.first]) kd = PK_FUSED;
         m->prof_ms[kd] += ms;
         m->prof_launches[kd] += 1;
         if (m->prof_op_ms.size() < m->def.ops.size()) { m->prof_op_ms.resize(m->def.ops.size(), 0.0); m->prof_op_n.resize(m->def.ops.size(), 0); }
@@ -676,10 +723,13 @@ int mi355_model_profile_ops(mi355_model_t m, int B, int H, int W, int max_ops, d
 int mi355_model_traffic_kinds(mi355_model_t m, int B, int H, int W, double* bytes_by_kind, double* macs_by_kind, int n) {
     MI355_REQUIRE(m && bytes_by_kind && macs_by_kind && n >= PK_COUNT, "traffic_kinds: need arrays of >= %d", PK_COUNT);
     for (int i = 0; i < PK_COUNT; ++i) { bytes_by_kind[i] = 0; macs_by_kind[i] = 0; }
-    plan_slots(m, B, H, W);
     SlotState S[SLOT_COUNT];
-    for (const Op& op : m->def.ops) {
-        const int kd = prof_kind(op);
+    int fused_left = 0;   // > 0 while walking the two ops of a pair the executor runs as one fused kernel
+    for (size_t oi = 0; oi < m->def.ops.size(); ++oi) {
+        const Op& op = m->def.ops[oi];
+        int kd = prof_kind(op);
+        if (fused_left == 0 && op.in != SLOT_NONE && can_fuse(m, oi, S[op.in].h, S[op.in].w)) fused_left = 2;
+        if (fused_left > 0) { kd = PK_FUSED; --fused_left; }
         switch (op.kind) {
             case OP_STEM: {
                 const int ho = conv_out(H, 3, 2), wo = conv_out(W, 3, 2);
@@ -728,6 +778,15 @@ int mi355_model_traffic(mi355_model_t m, int B, int H, int W, double* act_bytes,
     if (macs) *macs = tm;
     if (weight_bytes) *weight_bytes = (double)m->blob.size();
     return OK;
+}
+
+int mi355_gemm_bf16(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int ldw, int act,
+                    void* stream) {
+    MI355_REQUIRE(A && W && bias && out, "gemm_bf16: null pointer");
+    GemmArgs a{};
+    a.A = (const bf16_t*)A; a.lda = K; a.W = (const bf16_t*)W; a.ldw = ldw; a.bias = bias;
+    a.out = out; a.ldo = N; a.out_f32 = 0; a.M = M; a.N = N; a.K = K; a.act = act; a.rows_per_img = 1; a.res_n = N;
+    return launch_gemm_bf16(a, (hipStream_t)stream);
 }
 
 int mi355_conv_input_silu(const float* x, const float* w, int B, int H, int W, float* out, void* stream) {

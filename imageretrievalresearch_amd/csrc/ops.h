@@ -23,6 +23,22 @@ struct GemmArgs {
 };
 int launch_gemm_bf16(const GemmArgs& a, hipStream_t st);
 
+// ---- fused expand(1x1, MFMA) -> depthwise -> SE squeeze for whole-image tiles (fused_mbconv.hip) ------------
+struct FusedArgs {
+    const bf16_t* X;      // [B][H][W][Cin] block input
+    const bf16_t* We;     // expand weights, GEMM packing [midPad16][Kp]
+    const float* be;      // expand bias [midPad16]
+    const bf16_t* Wd;     // depthwise weights [k*k][mid]
+    const float* bd;      // depthwise bias [mid]
+    bf16_t* D;            // [B][Ho][Wo][mid] depthwise output
+    float* pool;          // optional [B][mid]: complete per-channel sums of D (SE squeeze, nblk = 1)
+    int H, W, Cin, Kp, mid, Ho, Wo;
+    int act_e, act_d;
+    int debug_skip;       // diagnosis only: bit0 skip the expand GEMM phase, bit1 skip the depthwise phase
+};
+bool fused_late_supported(int H, int W, int Cin, int mid, int k, int stride);
+int launch_fused_late(const FusedArgs& a, int B, int k, int stride, hipStream_t st);
+
 // ---- convolution-side kernels (conv_kernels.hip) -----------------------------------------------
 // Stem: x [B][3][H][W] fp32 NCHW -> out [B][Ho][Wo][Cout] bf16, 3x3 stride 2 pad 1, + bias + act.
 // w [3*3*3][Cout] fp32 laid out (ky, kx, ci) major, bias fp32 [Cout].

@@ -221,7 +221,7 @@ class MI355Model(nn.Module):
         by = (C.c_double * 8)()
         mc = (C.c_double * 8)()
         check(lib().mi355_model_traffic_kinds(self._handle, B, H, W, by, mc, 8))
-        kinds = ["stem", "gemm", "dw", "se", "other", "attn", "ln"]
+        kinds = ["stem", "gemm", "dw", "se", "other", "attn", "ln", "fused"]
         return {"act_bytes": a.value, "weight_bytes": w.value, "macs": m.value,
                 "bytes_by_kind": dict(zip(kinds, list(by))), "macs_by_kind": dict(zip(kinds, list(mc)))}
 
@@ -229,7 +229,7 @@ class MI355Model(nn.Module):
         ms = (C.c_double * 8)()
         n = (C.c_int64 * 8)()
         check(lib().mi355_model_profile_read(self._handle, ms, n, 8))
-        kinds = ["stem", "gemm", "dw", "se", "other", "attn", "ln"]
+        kinds = ["stem", "gemm", "dw", "se", "other", "attn", "ln", "fused"]
         return {k: {"ms": ms[i], "launches": n[i]} for i, k in enumerate(kinds)}
 
     def profile_ops(self, B: int, H: int = 224, W: int = 224):
@@ -240,7 +240,7 @@ class MI355Model(nn.Module):
         kd = (C.c_int * n)()
         lab = C.create_string_buffer(n * 64)
         cnt = lib().mi355_model_profile_ops(self._handle, B, H, W, n, ms, by, kd, lab, 64)
-        kinds = ["stem", "gemm", "dw", "se", "other", "attn", "ln"]
+        kinds = ["stem", "gemm", "dw", "se", "other", "attn", "ln", "fused"]
         return [(lab.raw[i * 64:(i + 1) * 64].split(b"\0")[0].decode(), kinds[kd[i]], ms[i], by[i]) for i in range(cnt)]
 
     def enable_taps(self, on: bool = True):

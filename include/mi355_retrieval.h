@@ -156,10 +156,12 @@ int mi355_model_traffic(mi355_model_t m, int B, int H, int W, double* act_bytes,
                         double* macs);
 
 /* Per-kernel-family view of the same model, for the roofline of the dominant kernel.  Arrays of n >= 8
- * doubles indexed by kind: 0 stem, 1 1x1-conv GEMM, 2 depthwise, 3 SE, 4 other, 5 window attention, 6 layernorm. */
+ * doubles indexed by kind: 0 stem, 1 1x1-conv GEMM, 2 depthwise, 3 SE, 4 other, 5 window attention, 6 layernorm,
+ * 7 fused expand+depthwise (pairs the executor runs as one kernel; bytes are still the layer-granular model). */
 int mi355_model_traffic_kinds(mi355_model_t m, int B, int H, int W, double* bytes_by_kind, double* macs_by_kind, int n);
 
 /* Executor options: "microbatch" (images per pass through the layer plan; 0 = whole batch),
+ * "fuse" (1 = run expand+depthwise pairs on whole-image tiles as one LDS-resident kernel; default 1),
  * "profile" (1 = bracket every op with hipEvents on the launch stream; resets the accumulators). */
 int mi355_model_set_option(mi355_model_t m, const char* key, int64_t value);
 /* Accumulated per-kind kernel time (ms) and launch counts since "profile" was enabled; synchronises. */
@@ -170,6 +172,12 @@ int mi355_model_profile_read(mi355_model_t m, double* ms_by_kind, int64_t* launc
  * (callers size the arrays with max_ops >= that; 1024 is always enough).  Developer/bench tool. */
 int mi355_model_profile_ops(mi355_model_t m, int B, int H, int W, int max_ops, double* avg_ms, double* bytes,
                             int* kinds, char* labels, int label_stride);
+
+/* Stand-alone 1x1-conv / linear kernel (the model executor's GEMM): out[M][N] bf16 = act(A[M][K] bf16 * W^T + bias).
+ * W is bf16 [ceil16(N)][ldw] with ldw = K rounded up to 32, zero padded; bias fp32 [ceil16(N)]; K, N multiples of 8.
+ * act: 0 none, 1 SiLU, 2 ReLU, 3 ReLU6, 4 GELU, 5 sigmoid. */
+int mi355_gemm_bf16(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int ldw, int act,
+                    void* stream);
 
 /* conv_input pre-stem (inference/inference.py:103-105): out = SiLU(Conv2d(3,3,3,1,1,bias=False)(x)),
  * x/out [B][3][H][W] fp32 NCHW, w [3][3][3][3] fp32 (device). */

@@ -8,6 +8,10 @@ name = sys.argv[1] if len(sys.argv) > 1 else "efficientnet_b3a"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 dev = "cuda:0"
 model = M.create_model(name, num_classes=0).to(dev).eval()
+import os
+for kv in os.environ.get("MI355_OPTS", "").split(","):
+    if "=" in kv:
+        model.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 x = M.synth_fill(B * 3 * 224 * 224, 1, synth.UNIFORM, dev).view(B, 3, 224, 224)
 for _ in range(3):
     model(x)
