@@ -502,9 +502,6 @@ int swin_exec(const ModelDef&, const Op&, ExecCtx&) { set_error("swin ops not bu
 int swin_pack(Packer&, Op&) { set_error("swin ops not built"); return ERR_UNSUPPORTED; }
 int build_swin_base(ModelDef&) { set_error("swin_base_patch4_window7_224 not built yet"); return ERR_UNSUPPORTED; }
 #endif
-#ifndef MI355_HAVE_REXNET
-int build_rexnet(ModelDef&, double) { set_error("rexnet not built yet"); return ERR_UNSUPPORTED; }
-#endif
 }  // namespace mi355
 
 // ====================================================================================== C ABI

@@ -295,8 +295,11 @@ class MI355Model(nn.Module):
         # a head that is neither Linear nor Identity (user-assigned module): apply it on the pooled features
         head = self
         for p in _HEAD_PATH[self.family].split("."):
-            head = getattr(head, p)
-        if not isinstance(head, (nn.Linear, nn.Identity)):
+            nxt = getattr(head, p, None)
+            if nxt is None:        # e.g. rexnet `model.head = Identity()`: there is no `.fc` below it
+                break
+            head = nxt
+        if not isinstance(head, (nn.Linear, nn.Identity, ClassifierHead)):
             out = head(out)
         return out
 

@@ -14,5 +14,5 @@ Pinning status:
   arithmetic lives in timm==0.4.12 (requirements.txt:164), which is neither vendored in the
   reference nor installed here, and the reference holds no test or fixture for it.  The
   restatement follows timm 0.4.12's published structure and is anchored by exact parameter
-  counts (efficientnet_b3 12 233 232; rexnet_150/200 9 738 358 / 16 365 244... see each module).
+  counts (efficientnet_b3 12 233 232; rexnet_150/200 9.73 M / 16.37 M; swin_base 87.77 M — see each module).
 """

@@ -1,0 +1,84 @@
+"""RexNet (rexnet_150 = the reference's default model, rexnet_200 = BASELINE configs[2]): HIP executor vs the CPU oracle.
+Odd channel counts (54, 77, 167, ...) exercise the pad-to-8 layout and the partial-channel shortcut.
+Backbone parity is UNPINNED against timm itself (see oracle/__init__.py)."""
+import numpy as np
+import pytest
+import torch
+
+import imageretrievalresearch_amd as M
+from imageretrievalresearch_amd import synth
+from oracle import rank as orank, rexnet
+from test_effnet_gpu import images, rel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL_TAP_SIM = 2.5e-2      # ReLU6 clipping + 16 blocks: bf16 rounding flips compound a little faster than in effnet
+TOL_EMB_FP32 = 5e-2
+
+
+@pytest.mark.parametrize("name,wm", [("rexnet_150", 1.5), ("rexnet_200", 2.0)])
+def test_rexnet_blocks_and_embedding_match_oracle(name, wm):
+    sd = rexnet.init_state_dict(4, wm)
+    model = M.create_model(name).to(DEV).eval()
+    model.load_state_dict(sd, strict=True)
+    x = torch.from_numpy(images(21, 2))
+    taps = {}
+    want = rexnet.forward_features(sd, x, wm, sim_bf16=True, taps=taps)
+    taps["head"] = want
+    model.enable_taps(True)
+    got = model.forward_features(x.to(DEV))
+    worst = 0.0
+    for tname, ref in taps.items():
+        t = model.read_tap(tname).cpu()
+        assert t.shape == ref.shape, (tname, t.shape, ref.shape)
+        e = rel(t, ref)
+        worst = max(worst, e)
+        assert e < TOL_TAP_SIM, f"{name} tap {tname}: rel L2 {e:.3e}"
+    model.enable_taps(False)
+    print(name, "worst tap rel L2", worst)
+    assert got.shape == want.shape and rel(got.cpu(), want) < TOL_TAP_SIM
+    # train/train.py:194-195 call shape: fm = forward_features(x); lbl = head(fm)
+    lbl = model.head(got)
+    assert lbl.shape == (2, 1000)
+    want_logits = rexnet.forward(sd, x, wm, sim_bf16=True)
+    out = model(x.to(DEV))
+    assert rel(out.cpu(), want_logits) < 3e-2
+    f32 = rexnet.forward_features(sd, x, wm).mean((2, 3))
+    pooled, _ = model.embed(x.to(DEV))
+    assert rel(pooled.cpu(), f32) < TOL_EMB_FP32
+    assert torch.nn.functional.cosine_similarity(pooled.cpu(), f32).min() > 0.998
+    assert model.head.fc.in_features == model.num_features         # inference/inference.py:140
+
+
+def test_rexnet200_contrastive_and_pair_cosine_on_embeddings():
+    """BASELINE configs[2]: contrastive_loss.py / cosine parity on rexnet_200 (B, 2560) embeddings."""
+    sd = rexnet.init_state_dict(4, 2.0, num_classes=0)
+    model = M.create_model("rexnet_200", num_classes=0).to(DEV).eval()
+    model.load_state_dict(sd, strict=True)
+    xa = torch.from_numpy(images(31, 4)).to(DEV)
+    xb = torch.from_numpy(images(32, 4)).to(DEV)
+    ea, eb = model(xa), model(xb)
+    assert ea.shape == (4, 2560)
+    na, nb = ea.cpu().numpy(), eb.cpu().numpy()
+    for label, mean in ((1.0, True), (0.0, False)):
+        got = M.ContrastiveLoss(0.5)(ea, eb, label, mean).item()
+        want = float(orank.contrastive_loss(na, nb, label, 0.5, mean))
+        assert got == pytest.approx(want, rel=1e-5, abs=1e-7)
+    np.testing.assert_allclose(M.pair_cosine(ea, eb).cpu().numpy(), orank.pair_cosine(na, nb), atol=1e-5)
+    v, i = M.cosine_topk(ea, eb, 3)
+    wv, wi = orank.rank_topk(na, nb, 3)
+    np.testing.assert_allclose(v.cpu().numpy(), wv, atol=1e-5)
+
+
+def test_rexnet_head_identity_and_determinism():
+    model = M.create_model("rexnet_150").to(DEV).eval()
+    x = torch.from_numpy(images(41, 3)).to(DEV)
+    a = model(x)
+    assert torch.equal(a, model(x)) and a.shape == (3, 1000)
+    model.head = torch.nn.Identity()                    # notebook raw :190 idiom
+    e = model(x)
+    assert e.shape == (3, 1920)
+    model.set_option("fuse", 0)
+    e2 = model(x)
+    model.set_option("fuse", 1)
+    assert rel(e2, e) < 1e-2                            # fused and unfused executors agree to rounding
