@@ -1,7 +1,7 @@
 // Model object behind the C ABI: tensor table, one-time weight pack (BN fold -> bf16 -> kernel layout),
 // arena, and the executor that walks the op plan launching the HIP kernels on the caller's stream.
 // Replaces timm.create_model(...) + .forward/.forward_features (see include/mi355_retrieval.h).
-#include "model.h"
+#include "model_exec.h"
 #include "../../include/mi355_retrieval.h"
 
 #include <string.h>
@@ -10,112 +10,7 @@
 
 namespace mi355 {
 
-// implemented in swin_kernels.hip
-int swin_exec(const ModelDef& def, const Op& op, struct ExecCtx& cx);
-
-static inline uint16_t f2bf_host(float f) {
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-static inline float bf_round_host(float f) {
-    uint32_t u = ((uint32_t)f2bf_host(f)) << 16;
-    float r;
-    memcpy(&r, &u, 4);
-    return r;
-}
-
-struct SlotState {
-    size_t off = 0, bytes = 0;
-    int h = 0, w = 0, c = 0;
-};
-
-struct TapBuf {
-    void* ptr = nullptr;
-    size_t bytes = 0;
-    int B = 0, h = 0, w = 0, c = 0, c_real = 0;
-};
-
-enum { PK_STEM = 0, PK_GEMM, PK_DW, PK_SE, PK_OTHER, PK_ATTN, PK_LN, PK_FUSED, PK_COUNT };
-
-}  // namespace mi355
-
-using namespace mi355;
-
-struct mi355_model {
-    ModelDef def;
-    std::vector<char> blob;
-    void* dev_blob = nullptr;
-    size_t dev_blob_bytes = 0;
-    bool packed = false;
-    void* arena = nullptr;
-    size_t arena_bytes = 0;
-    SlotState slots[SLOT_COUNT];
-    int microbatch = 0;
-    bool fuse = true;           // fused expand+depthwise for whole-image tiles (option "fuse")
-    int fuse_debug = 0;
-    int pool_nblk = 0;          // squeeze partials per image produced by the last depthwise stage
-    bool taps = false;
-    std::map<std::string, TapBuf> tapbufs;
-    // per-kind profiling with hipEvents (option "profile")
-    bool profile = false;
-    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;  // (op index, events)
-    std::vector<char> prof_fused;   // op index -> executed as a fused expand+depthwise pair
-    std::vector<double> prof_op_ms;
-    std::vector<long> prof_op_n;
-    double prof_ms[PK_COUNT] = {0};
-    long prof_launches[PK_COUNT] = {0};
-};
-
-namespace mi355 {
-
-struct ExecCtx {
-    mi355_model* m;
-    hipStream_t st;
-    int nb, H, W;          // chunk batch, input size
-    const float* x;        // chunk input (NCHW fp32)
-    int b0, B;             // chunk offset / full batch (for taps)
-    char* base() const { return (char*)m->arena; }
-    void* slot_ptr(int s) const { return s == SLOT_NONE ? nullptr : base() + m->slots[s].off; }
-    const char* w(size_t off) const { return (const char*)m->dev_blob + off; }
-};
-
-// ------------------------------------------------------------------------------------ packing
-struct Packer {
-    mi355_model* m;
-    std::vector<char>& blob;
-    size_t alloc(size_t bytes) {
-        const size_t off = align_up(blob.size(), 256);
-        blob.resize(off + bytes, 0);
-        return off;
-    }
-    const TensorSpec* get(const std::string& name) {
-        auto it = m->def.index.find(name);
-        if (it == m->def.index.end()) { set_error("pack: unknown tensor '%s'", name.c_str()); return nullptr; }
-        const TensorSpec& t = m->def.tensors[it->second];
-        if (!t.set) { set_error("pack: tensor '%s' was never set (mi355_model_set_tensor)", name.c_str()); return nullptr; }
-        return &t;
-    }
-    // per-output-channel (scale, shift) of an eval-mode BN, in the same fp32 op order as the oracle
-    bool bn_fold(const std::string& bn, float eps, int n, std::vector<float>& scale, std::vector<float>& shift) {
-        scale.assign(n, 1.f);
-        shift.assign(n, 0.f);
-        if (bn.empty()) return true;
-        const TensorSpec *g = get(bn + ".weight"), *b = get(bn + ".bias"), *mu = get(bn + ".running_mean"),
-                         *var = get(bn + ".running_var");
-        if (!g || !b || !mu || !var) return false;
-        for (int i = 0; i < n; ++i) {
-            const float s = g->data[i] / sqrtf(var->data[i] + eps);
-            scale[i] = s;
-            shift[i] = b->data[i] - mu->data[i] * s;
-        }
-        return true;
-    }
-};
-
-static int pack_gemm(Packer& pk, Op& op) {
+int pack_gemm(Packer& pk, Op& op) {
     const TensorSpec* w = pk.get(op.w_name);
     if (!w) return ERR_STATE;
     const int N = op.cout_real, K = op.cin_real;
@@ -257,8 +152,10 @@ static size_t plan_slots(mi355_model* m, int nb, int H, int W) {
             default: {
                 // swin ops: sizes are declared by the builder through cin/cout/tokens_h
                 const int th = op.tokens_h;
-                S[op.out].h = th; S[op.out].w = th; S[op.out].c = op.cout;
-                need(op.out, (size_t)nb * th * th * op.cout * 2);
+                if (op.out != SLOT_NONE) {
+                    S[op.out].h = th; S[op.out].w = th; S[op.out].c = op.cout;
+                    need(op.out, (size_t)nb * th * th * op.cout * 2);
+                }
                 break;
             }
         }
@@ -294,7 +191,8 @@ static int prof_kind(const Op& op) {
         case OP_DW: return PK_DW;
         case OP_SE: return PK_SE;
         case OP_WINATTN: return PK_ATTN;
-        case OP_LAYERNORM: case OP_PATCH_MERGE_LN: return PK_LN;
+        case OP_LAYERNORM: case OP_PATCH_MERGE_LN: case OP_TOKEN_MEAN: return PK_LN;
+        case OP_PATCH_EMBED: return PK_STEM;
         default: return PK_OTHER;
     }
 }
@@ -408,7 +306,7 @@ static int run_backbone(ExecCtx& cx) {
                 break;
             }
             case OP_SE: break;
-            default: S[op.out].h = op.tokens_h; S[op.out].w = op.tokens_h; S[op.out].c = op.cout; break;
+            default: if (op.out != SLOT_NONE) { S[op.out].h = op.tokens_h; S[op.out].w = op.tokens_h; S[op.out].c = op.cout; } break;
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (m->profile) {
@@ -494,14 +392,6 @@ static int forward_impl(mi355_model* m, const float* x, int B, int H, int W, flo
     return OK;
 }
 
-}  // namespace mi355
-
-namespace mi355 {
-#ifndef MI355_HAVE_SWIN
-int swin_exec(const ModelDef&, const Op&, ExecCtx&) { set_error("swin ops not built"); return ERR_UNSUPPORTED; }
-int swin_pack(Packer&, Op&) { set_error("swin ops not built"); return ERR_UNSUPPORTED; }
-int build_swin_base(ModelDef&) { set_error("swin_base_patch4_window7_224 not built yet"); return ERR_UNSUPPORTED; }
-#endif
 }  // namespace mi355
 
 // ====================================================================================== C ABI
@@ -703,7 +593,7 @@ int mi355_model_profile_ops(mi355_model_t m, int B, int H, int W, int max_ops, d
             }
             case OP_SE: snprintf(lab, sizeof lab, "se C%d rd%d", op.cin_real, op.rd); break;
             default: {
-                S[op.out].h = op.tokens_h; S[op.out].w = op.tokens_h;
+                if (op.out != SLOT_NONE) { S[op.out].h = op.tokens_h; S[op.out].w = op.tokens_h; }
                 by = (double)B * op.tokens_h * op.tokens_h * (op.cin_real + op.cout_real) * 2;
                 snprintf(lab, sizeof lab, "op%d C%d->%d t%d", (int)op.kind, op.cin_real, op.cout_real, op.tokens_h);
                 break;
@@ -755,9 +645,13 @@ int mi355_model_traffic_kinds(mi355_model_t m, int B, int H, int W, double* byte
                 macs_by_kind[kd] += (double)B * 2.0 * op.cin_real * op.rd;
                 break;
             default: {
-                S[op.out].h = op.tokens_h; S[op.out].w = op.tokens_h;
+                if (op.out != SLOT_NONE) { S[op.out].h = op.tokens_h; S[op.out].w = op.tokens_h; }
                 const double t = (double)op.tokens_h * op.tokens_h;
-                bytes_by_kind[kd] += B * t * (op.cin_real + op.cout_real) * 2;
+                if (op.kind == OP_PATCH_EMBED) bytes_by_kind[kd] += (double)B * (3.0 * H * W * 4 + t * op.cout_real * 2);
+                else if (op.kind == OP_TOKEN_MEAN) bytes_by_kind[kd] += B * t * op.cin_real * 2;
+                else bytes_by_kind[kd] += B * t * (op.cin_real + op.cout_real) * 2;
+                if (op.kind == OP_WINATTN) macs_by_kind[kd] += B * t * 49.0 * op.cout_real * 2;   // QK^T + PV
+                if (op.kind == OP_PATCH_EMBED) macs_by_kind[kd] += B * t * 48.0 * op.cout_real;
                 break;
             }
         }

@@ -1,0 +1,117 @@
+// Executor-side structures shared by model.hip and swin_kernels.hip: the model object behind the C ABI,
+// the per-forward execution context and the weight packer.
+#pragma once
+#include "model.h"
+
+#include <string.h>
+
+namespace mi355 {
+
+// implemented in swin_kernels.hip
+int swin_exec(const ModelDef& def, const Op& op, struct ExecCtx& cx);
+
+static inline uint16_t f2bf_host(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf_round_host(float f) {
+    uint32_t u = ((uint32_t)f2bf_host(f)) << 16;
+    float r;
+    memcpy(&r, &u, 4);
+    return r;
+}
+
+struct SlotState {
+    size_t off = 0, bytes = 0;
+    int h = 0, w = 0, c = 0;
+};
+
+struct TapBuf {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    int B = 0, h = 0, w = 0, c = 0, c_real = 0;
+};
+
+enum { PK_STEM = 0, PK_GEMM, PK_DW, PK_SE, PK_OTHER, PK_ATTN, PK_LN, PK_FUSED, PK_COUNT };
+
+}  // namespace mi355
+
+using namespace mi355;
+
+struct mi355_model {
+    ModelDef def;
+    std::vector<char> blob;
+    void* dev_blob = nullptr;
+    size_t dev_blob_bytes = 0;
+    bool packed = false;
+    void* arena = nullptr;
+    size_t arena_bytes = 0;
+    SlotState slots[SLOT_COUNT];
+    int microbatch = 0;
+    bool fuse = true;           // fused expand+depthwise for whole-image tiles (option "fuse")
+    int fuse_debug = 0;
+    int pool_nblk = 0;          // squeeze partials per image produced by the last depthwise stage
+    bool taps = false;
+    std::map<std::string, TapBuf> tapbufs;
+    // per-kind profiling with hipEvents (option "profile")
+    bool profile = false;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> prof_events;  // (op index, events)
+    std::vector<char> prof_fused;   // op index -> executed as a fused expand+depthwise pair
+    std::vector<double> prof_op_ms;
+    std::vector<long> prof_op_n;
+    double prof_ms[PK_COUNT] = {0};
+    long prof_launches[PK_COUNT] = {0};
+};
+
+namespace mi355 {
+
+struct ExecCtx {
+    mi355_model* m;
+    hipStream_t st;
+    int nb, H, W;          // chunk batch, input size
+    const float* x;        // chunk input (NCHW fp32)
+    int b0, B;             // chunk offset / full batch (for taps)
+    char* base() const { return (char*)m->arena; }
+    void* slot_ptr(int s) const { return s == SLOT_NONE ? nullptr : base() + m->slots[s].off; }
+    const char* w(size_t off) const { return (const char*)m->dev_blob + off; }
+};
+
+// ------------------------------------------------------------------------------------ packing
+struct Packer {
+    mi355_model* m;
+    std::vector<char>& blob;
+    size_t alloc(size_t bytes) {
+        const size_t off = align_up(blob.size(), 256);
+        blob.resize(off + bytes, 0);
+        return off;
+    }
+    const TensorSpec* get(const std::string& name) {
+        auto it = m->def.index.find(name);
+        if (it == m->def.index.end()) { set_error("pack: unknown tensor '%s'", name.c_str()); return nullptr; }
+        const TensorSpec& t = m->def.tensors[it->second];
+        if (!t.set) { set_error("pack: tensor '%s' was never set (mi355_model_set_tensor)", name.c_str()); return nullptr; }
+        return &t;
+    }
+    // per-output-channel (scale, shift) of an eval-mode BN, in the same fp32 op order as the oracle
+    bool bn_fold(const std::string& bn, float eps, int n, std::vector<float>& scale, std::vector<float>& shift) {
+        scale.assign(n, 1.f);
+        shift.assign(n, 0.f);
+        if (bn.empty()) return true;
+        const TensorSpec *g = get(bn + ".weight"), *b = get(bn + ".bias"), *mu = get(bn + ".running_mean"),
+                         *var = get(bn + ".running_var");
+        if (!g || !b || !mu || !var) return false;
+        for (int i = 0; i < n; ++i) {
+            const float s = g->data[i] / sqrtf(var->data[i] + eps);
+            scale[i] = s;
+            shift[i] = b->data[i] - mu->data[i] * s;
+        }
+        return true;
+    }
+};
+
+int pack_gemm(Packer& pk, Op& op);
+
+}  // namespace mi355

@@ -1,0 +1,485 @@
+// Swin kernels: patch embed (+LN), LayerNorm (plain / 2x2 patch-merge gather / final LN + token mean) and the
+// MFMA window-attention kernel with fused relative-position bias, shift mask and softmax.  gfx950 only.
+//
+// Attention maps one wave to one (image, window, head): 49 tokens x head_dim 32.  S^T = K Q^T runs on
+// mfma_f32_16x16x32_bf16 with BOTH operands loaded straight from the qkv tensor in fragment layout (a lane needs
+// 16 contiguous bytes of one token row); with keys on the MFMA rows a lane ends up with 16 keys of ONE query, so
+// the softmax reduction is in-lane + two xor-shuffles, and the probabilities are already in B-operand layout for
+// O^T = V^T P^T (k permuted the same way on the V^T side).  Only V goes through LDS (transposed, 4.6 KB / wave).
+#include "model_exec.h"
+
+namespace mi355 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void sw_unpack8(u32x4 v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ u32x4 sw_pack8(const float* f) {
+    u32x4 o;
+    o.x = pack2bf(f[0], f[1]); o.y = pack2bf(f[2], f[3]); o.z = pack2bf(f[4], f[5]); o.w = pack2bf(f[6], f[7]);
+    return o;
+}
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// =====================================================================================
+// patch embed: conv 4x4 stride 4 (3 -> 128) + bias, then LayerNorm(128).  Block = 16 patches x 16 channel groups.
+// w [48][128] fp32 (k = ci*16 + dy*4 + dx), values pre-rounded to bf16.
+// =====================================================================================
+__global__ __launch_bounds__(256) void k_patch_embed(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16_t* __restrict__ out, int H,
+                                                     int W, int gw, int L, float eps) {
+    __shared__ float xin[16][48];
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * 16;
+    for (int i = threadIdx.x; i < 16 * 48; i += 256) {
+        const int pi = i / 48, k = i - pi * 48;
+        const int pp = p0 + pi;
+        float v = 0.f;
+        if (pp < L) {
+            const int py = pp / gw, px = pp - py * gw;
+            const int ci = k >> 4, dy = (k >> 2) & 3, dx = k & 3;
+            v = x[(((size_t)b * 3 + ci) * H + 4 * py + dy) * W + 4 * px + dx];
+        }
+        xin[pi][k] = v;
+    }
+    __syncthreads();
+    const int pi = threadIdx.x >> 4, cg = threadIdx.x & 15;
+    float acc[8];
+    {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + cg * 8);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + cg * 8 + 4);
+        acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w; acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
+    }
+#pragma unroll 4
+    for (int k = 0; k < 48; ++k) {
+        const float xv = xin[pi][k];
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + k * 128 + cg * 8);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(w + k * 128 + cg * 8 + 4);
+        acc[0] += xv * w0.x; acc[1] += xv * w0.y; acc[2] += xv * w0.z; acc[3] += xv * w0.w;
+        acc[4] += xv * w1.x; acc[5] += xv * w1.y; acc[6] += xv * w1.z; acc[7] += xv * w1.w;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += acc[j];
+    const float mean = group_sum<16>(s) * (1.0f / 128.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { acc[j] -= mean; q += acc[j] * acc[j]; }
+    const float rstd = rsqrtf(group_sum<16>(q) * (1.0f / 128.0f) + eps);
+    const int pp = p0 + pi;
+    if (pp < L) {
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = acc[j] * rstd * gamma[cg * 8 + j] + beta[cg * 8 + j];
+        *reinterpret_cast<u32x4*>(out + ((size_t)b * L + pp) * 128 + cg * 8) = sw_pack8(y);
+    }
+}
+
+// =====================================================================================
+// LayerNorm over the channel dim of [rows][C] bf16.  LPR lanes per row, VPL 16-byte vectors per lane:
+// C = LPR * VPL * 8.  MERGE: the input row is the 2x2 patch-merge concat [x(2y,2x), x(2y+1,2x), x(2y,2x+1),
+// x(2y+1,2x+1)] of a [B][2*gh][2*gw][C/4] tensor (timm PatchMerging order), gathered on load.
+// =====================================================================================
+template <int LPR, int VPL, bool MERGE>
+__global__ __launch_bounds__(256) void k_layernorm(const bf16_t* __restrict__ in, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, bf16_t* __restrict__ out, long rows,
+                                                   int gh, int gw, float eps) {
+    constexpr int C = LPR * VPL * 8;
+    constexpr int RPB = 256 / LPR;   // rows per block
+    const int sub = threadIdx.x % LPR;
+    const long row = (long)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool live = row < rows;
+    float v[VPL][8];
+    const bf16_t* src[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int vec = sub + i * LPR;   // vector index within the row
+        if (MERGE) {
+            constexpr int C4 = C / 4;                 // source channels
+            const int part = (vec * 8) / C4, off = (vec * 8) - part * C4;
+            const long r = live ? row : 0;
+            const long bimg = r / ((long)gh * gw);
+            const int rem = (int)(r - bimg * gh * gw);
+            const int oy = rem / gw, ox = rem - oy * gw;
+            const int sy = 2 * oy + (part & 1), sx = 2 * ox + (part >> 1);
+            src[i] = in + ((bimg * (2 * gh) + sy) * (2 * gw) + sx) * (long)C4 + off;
+        } else {
+            src[i] = in + (live ? row : 0) * (long)C + vec * 8;
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        sw_unpack8(*reinterpret_cast<const u32x4*>(src[i]), v[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[i][j];
+    }
+    const float mean = group_sum<LPR>(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[i][j] -= mean; q += v[i][j] * v[i][j]; }
+    const float rstd = rsqrtf(group_sum<LPR>(q) * (1.0f / C) + eps);
+    if (!live) return;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c0 = (sub + i * LPR) * 8;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c0), g1 = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c0), b1 = *reinterpret_cast<const f32x4*>(beta + c0 + 4);
+        float y[8] = {v[i][0] * rstd * g0.x + b0.x, v[i][1] * rstd * g0.y + b0.y, v[i][2] * rstd * g0.z + b0.z,
+                      v[i][3] * rstd * g0.w + b0.w, v[i][4] * rstd * g1.x + b1.x, v[i][5] * rstd * g1.y + b1.y,
+                      v[i][6] * rstd * g1.z + b1.z, v[i][7] * rstd * g1.w + b1.w};
+        *reinterpret_cast<u32x4*>(out + row * (long)C + c0) = sw_pack8(y);
+    }
+}
+
+template <bool MERGE>
+static int launch_ln(const bf16_t* in, const float* g, const float* b, bf16_t* out, long rows, int C, int gh, int gw,
+                     float eps, hipStream_t st) {
+#define LN_CASE(LPR, VPL)                                                                                  \
+    hipLaunchKernelGGL((k_layernorm<LPR, VPL, MERGE>), dim3((unsigned)cdiv(rows, 256 / LPR)), dim3(256), 0, st, in, g, b, \
+                       out, rows, gh, gw, eps)
+    switch (C) {
+        case 128: LN_CASE(16, 1); break;
+        case 256: LN_CASE(32, 1); break;
+        case 512: LN_CASE(64, 1); break;
+        case 1024: LN_CASE(64, 2); break;
+        case 2048: LN_CASE(64, 4); break;
+        default: set_error("layernorm: unsupported width %d", C); return ERR_UNSUPPORTED;
+    }
+#undef LN_CASE
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
+// final LayerNorm(C = 1024) + mean over the L tokens of an image -> pooled fp32 (+ bf16 copy).  One block per image;
+// wave w normalises tokens w, w+4, ... and the four per-wave partial sums are added in wave order.
+__global__ __launch_bounds__(256) void k_ln_token_mean(const bf16_t* __restrict__ in, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ pooled,
+                                                       bf16_t* __restrict__ pooled_bf16, int L, float eps) {
+    constexpr int C = 1024;
+    __shared__ float part[4][C];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+    for (int t = wave; t < L; t += 4) {
+        const bf16_t* src = in + ((size_t)b * L + t) * C;
+        float v[2][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            sw_unpack8(*reinterpret_cast<const u32x4*>(src + (lane + i * 64) * 8), v[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[i][j];
+        }
+        const float mean = group_sum<64>(s) * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[i][j] -= mean; q += v[i][j] * v[i][j]; }
+        const float rstd = rsqrtf(group_sum<64>(q) * (1.0f / C) + eps);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = (lane + i * 64) * 8 + j;
+                acc[i][j] += v[i][j] * rstd * gamma[c] + beta[c];
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[wave][(lane + i * 64) * 8 + j] = acc[i][j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float m = (part[0][c] + part[1][c] + part[2][c] + part[3][c]) / (float)L;
+        pooled[(size_t)b * C + c] = m;
+        pooled_bf16[(size_t)b * C + c] = f2bf(m);
+    }
+}
+
+// =====================================================================================
+// window attention.  qkv [B][L][3C] bf16 (channel = which*C + head*32 + d), out [B][L][C] bf16.
+// bias [heads][49][64] fp32 (dense relative-position bias, key dim padded to 64).
+// =====================================================================================
+constexpr int WA_N = 49;       // tokens per 7x7 window
+constexpr int WA_VLD = 72;     // Vt row stride (keys) in bf16
+
+__global__ __launch_bounds__(256) void k_win_attn(const bf16_t* __restrict__ qkv, const float* __restrict__ bias,
+                                                  bf16_t* __restrict__ out, int res, int C, int heads, int shift,
+                                                  long ntasks, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t Vt_all[4][32 * WA_VLD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long task = (long)blockIdx.x * 4 + wave;
+    if (task >= ntasks) return;          // whole wave exits together; no block-level barrier below
+    bf16_t* Vt = Vt_all[wave];
+    const int nwx = res / 7, nW = nwx * nwx;
+    const int h = (int)(task % heads);
+    const long bw = task / heads;
+    const int win = (int)(bw % nW);
+    const long b = bw / nW;
+    const int wy = win / nwx, wx = win - wy * nwx;
+    const int L = res * res, C3 = 3 * C;
+    const bf16_t* base = qkv + (size_t)b * L * C3 + h * 32;
+
+    // in-window index -> image token (undoing the cyclic shift) and shifted-frame region label
+    auto token_of = [&](int i) {
+        const int iy = i / 7, ix = i - iy * 7;
+        int y = wy * 7 + iy + shift, x = wx * 7 + ix + shift;
+        if (y >= res) y -= res;
+        if (x >= res) x -= res;
+        return y * res + x;
+    };
+    auto label_of = [&](int i) {
+        const int iy = i / 7, ix = i - iy * 7;
+        const int y = wy * 7 + iy, x = wx * 7 + ix;
+        const int rh = y < res - 7 ? 0 : (y < res - shift ? 1 : 2);
+        const int rw = x < res - 7 ? 0 : (x < res - shift ? 1 : 2);
+        return rh * 3 + rw;
+    };
+
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // ---- V^T -> LDS: Vt[d][key]; keys >= 49 are zero
+    for (int i = lane; i < 32 * WA_VLD / 2; i += 64) reinterpret_cast<unsigned*>(Vt)[i] = 0u;
+    for (int c = lane; c < WA_N * 4; c += 64) {
+        const int key = c >> 2, dp = (c & 3) * 8;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(base + (size_t)token_of(key) * C3 + 2 * C + dp);
+        const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Vt[(dp + j) * WA_VLD + key] = e[j];
+    }
+
+    // ---- S^T = K Q^T : A rows = keys, B cols = queries, contraction over d (32 = one k-step)
+    bf16x8 kf[4], qf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int i = t * 16 + fr;
+        u32x4 kv = {0u, 0u, 0u, 0u}, qv = {0u, 0u, 0u, 0u};
+        if (i < WA_N) {
+            const bf16_t* row = base + (size_t)token_of(i) * C3 + fq * 8;
+            qv = *reinterpret_cast<const u32x4*>(row);
+            kv = *reinterpret_cast<const u32x4*>(row + C);
+        }
+        kf[t] = *reinterpret_cast<bf16x8*>(&kv);
+        qf[t] = *reinterpret_cast<bf16x8*>(&qv);
+    }
+    f32x4 s[4][4];   // [key tile t][query tile u]; lane: query = 16u + fr, keys = 16t + 4*fq + r
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            s[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t], qf[u], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+
+    // ---- bias + mask + softmax over keys (in-lane 16 values, then across the 4 lane groups)
+    const float* bh = bias + (size_t)h * WA_N * 64;
+    bf16x8 pf[4][2];   // [query tile u][k-step]: P^T in B-operand layout
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int qi = u * 16 + fr;
+        const int qc = qi < WA_N ? qi : WA_N - 1;     // clamp padded queries to a valid row (result discarded)
+        const int ql = shift > 0 ? label_of(qc) : 0;
+        float v[4][4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k0 = t * 16 + fq * 4;
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(bh + (size_t)qc * 64 + k0);
+            const float sv[4] = {s[t][u].x, s[t][u].y, s[t][u].z, s[t][u].w};
+            const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + r;
+                float x = sv[r] * scale + bv[r];
+                if (shift > 0 && key < WA_N && label_of(key) != ql) x += -100.0f;
+                if (key >= WA_N) x = -INFINITY;
+                v[t][r] = x;
+                mx = fmaxf(mx, x);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[t][r] = __expf(v[t][r] - mx);
+                sum += v[t][r];
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 pk;
+            pk.x = pack2bf(v[2 * ks][0] * inv, v[2 * ks][1] * inv);
+            pk.y = pack2bf(v[2 * ks][2] * inv, v[2 * ks][3] * inv);
+            pk.z = pack2bf(v[2 * ks + 1][0] * inv, v[2 * ks + 1][1] * inv);
+            pk.w = pack2bf(v[2 * ks + 1][2] * inv, v[2 * ks + 1][3] * inv);
+            pf[u][ks] = *reinterpret_cast<bf16x8*>(&pk);
+        }
+    }
+
+    // ---- O^T = V^T P^T : A rows = d (two 16-row tiles), k = keys in the SAME permuted order as pf:
+    // element j of lane group fq in k-step ks is key 16*(2ks + (j>>2)) + 4*fq + (j&3)
+    f32x4 o[2][4];
+#pragma unroll
+    for (int vt = 0; vt < 2; ++vt)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) o[vt][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt) {
+            const bf16_t* vr = Vt + (vt * 16 + fr) * WA_VLD + 32 * ks + 4 * fq;
+            u32x4 a;
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(vr);
+            const u32x2 hi = *reinterpret_cast<const u32x2*>(vr + 16);
+            a.x = lo.x; a.y = lo.y; a.z = hi.x; a.w = hi.y;
+            const bf16x8 af = *reinterpret_cast<bf16x8*>(&a);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                o[vt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pf[u][ks], o[vt][u], 0, 0, 0);
+        }
+    }
+
+    // ---- store: lane holds query 16u + fr, d = 16vt + 4*fq + r
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int qi = u * 16 + fr;
+        if (qi >= WA_N) continue;
+        bf16_t* orow = out + ((size_t)b * L + token_of(qi)) * C + h * 32 + fq * 4;
+#pragma unroll
+        for (int vt = 0; vt < 2; ++vt) {
+            u32x2 w;
+            w.x = pack2bf(o[vt][u].x, o[vt][u].y);
+            w.y = pack2bf(o[vt][u].z, o[vt][u].w);
+            *reinterpret_cast<u32x2*>(orow + vt * 16) = w;
+        }
+    }
+}
+
+// =====================================================================================
+// packing + execution hooks used by model.hip
+// =====================================================================================
+static inline uint16_t f2bf_h(float f) { return f2bf_host(f); }
+
+int swin_pack(Packer& pk, Op& op) {
+    auto put_vec = [&](const std::string& name, int n, size_t& off) -> int {
+        const TensorSpec* t = pk.get(name);
+        if (!t) return ERR_STATE;
+        MI355_REQUIRE(t->numel() == n, "pack: %s has %lld elements, expected %d", name.c_str(), (long long)t->numel(), n);
+        off = pk.alloc((size_t)n * 4);
+        memcpy(pk.blob.data() + off, t->data.data(), (size_t)n * 4);
+        return OK;
+    };
+    switch (op.kind) {
+        case OP_PATCH_EMBED: {
+            const TensorSpec* w = pk.get(op.w_name);
+            if (!w) return ERR_STATE;
+            MI355_REQUIRE(w->numel() == 128 * 48, "pack: %s shape", op.w_name.c_str());
+            op.w_off = pk.alloc((size_t)48 * 128 * 4);
+            float* W = (float*)(pk.blob.data() + op.w_off);
+            for (int co = 0; co < 128; ++co)
+                for (int k = 0; k < 48; ++k) W[(size_t)k * 128 + co] = bf_round_host(w->data[(size_t)co * 48 + k]);
+            if (int e = put_vec(op.bias_name, 128, op.b_off)) return e;
+            if (int e = put_vec(op.w2_name, 128, op.w2_off)) return e;
+            return put_vec(op.bias2_name, 128, op.b2_off);
+        }
+        case OP_LAYERNORM: case OP_PATCH_MERGE_LN: case OP_TOKEN_MEAN: {
+            if (int e = put_vec(op.w_name, op.cout, op.w_off)) return e;
+            return put_vec(op.bias_name, op.cout, op.b_off);
+        }
+        case OP_WINATTN: {
+            const TensorSpec* t = pk.get(op.aux_name);
+            if (!t) return ERR_STATE;
+            const int ws = op.window, nh = op.heads, N = ws * ws;
+            MI355_REQUIRE(ws == 7 && t->numel() == (int64_t)(2 * ws - 1) * (2 * ws - 1) * nh, "pack: %s shape", op.aux_name.c_str());
+            op.aux_off = pk.alloc((size_t)nh * N * 64 * 4);
+            float* Bd = (float*)(pk.blob.data() + op.aux_off);
+            for (int hh = 0; hh < nh; ++hh)
+                for (int i = 0; i < N; ++i)
+                    for (int j = 0; j < N; ++j) {
+                        // relative_position_index[i][j] (timm WindowAttention.__init__)
+                        const int dy = i / ws - j / ws + ws - 1, dx = i % ws - j % ws + ws - 1;
+                        const int idx = dy * (2 * ws - 1) + dx;
+                        Bd[((size_t)hh * N + i) * 64 + j] = t->data[(size_t)idx * nh + hh];
+                    }
+            return OK;
+        }
+        default:
+            set_error("pack: unknown op kind %d", (int)op.kind);
+            return ERR_STATE;
+    }
+}
+
+int swin_exec(const ModelDef& def, const Op& op, ExecCtx& cx) {
+    mi355_model* m = cx.m;
+    SlotState* S = m->slots;
+    switch (op.kind) {
+        case OP_PATCH_EMBED: {
+            MI355_REQUIRE(cx.H == 224 && cx.W == 224, "swin needs 224x224 input");
+            const int gw = cx.W / 4, L = gw * (cx.H / 4);
+            hipLaunchKernelGGL(k_patch_embed, dim3(cdiv(L, 16), cx.nb), dim3(256), 0, cx.st, cx.x, (const float*)cx.w(op.w_off),
+                               (const float*)cx.w(op.b_off), (const float*)cx.w(op.w2_off), (const float*)cx.w(op.b2_off),
+                               (bf16_t*)cx.slot_ptr(op.out), cx.H, cx.W, gw, L, op.ln_eps);
+            MI355_LAUNCH_CHECK();
+            return OK;
+        }
+        case OP_LAYERNORM: {
+            const long rows = (long)cx.nb * op.tokens_h * op.tokens_h;
+            return launch_ln<false>((const bf16_t*)cx.slot_ptr(op.in), (const float*)cx.w(op.w_off), (const float*)cx.w(op.b_off),
+                                    (bf16_t*)cx.slot_ptr(op.out), rows, op.cout, 0, 0, op.ln_eps, cx.st);
+        }
+        case OP_PATCH_MERGE_LN: {
+            const long rows = (long)cx.nb * op.tokens_h * op.tokens_h;
+            return launch_ln<true>((const bf16_t*)cx.slot_ptr(op.in), (const float*)cx.w(op.w_off), (const float*)cx.w(op.b_off),
+                                   (bf16_t*)cx.slot_ptr(op.out), rows, op.cout, op.tokens_h, op.tokens_h, op.ln_eps, cx.st);
+        }
+        case OP_WINATTN: {
+            const int res = op.tokens_h, nW = (res / 7) * (res / 7);
+            const long ntasks = (long)cx.nb * nW * op.heads;
+            const int C = op.cout;
+            MI355_REQUIRE(C == op.heads * 32, "win_attn: head_dim must be 32");
+            hipLaunchKernelGGL(k_win_attn, dim3((unsigned)cdiv(ntasks, 4)), dim3(256), 0, cx.st, (const bf16_t*)cx.slot_ptr(op.in),
+                               (const float*)cx.w(op.aux_off), (bf16_t*)cx.slot_ptr(op.out), res, C, op.heads, op.shift, ntasks,
+                               0.17677669529663687f /* 32^-0.5 */);
+            MI355_LAUNCH_CHECK();
+            return OK;
+        }
+        case OP_TOKEN_MEAN: {
+            MI355_REQUIRE(op.cin == 1024, "token_mean: width %d unsupported", op.cin);
+            const int L = op.tokens_h * op.tokens_h;
+            hipLaunchKernelGGL(k_ln_token_mean, dim3(cx.nb), dim3(256), 0, cx.st, (const bf16_t*)cx.slot_ptr(op.in),
+                               (const float*)cx.w(op.w_off), (const float*)cx.w(op.b_off), (float*)cx.slot_ptr(SLOT_POOLED),
+                               (bf16_t*)cx.slot_ptr(SLOT_POOLED_BF16), L, op.ln_eps);
+            MI355_LAUNCH_CHECK();
+            return OK;
+        }
+        default:
+            set_error("exec: unknown op kind %d", (int)op.kind);
+            return ERR_STATE;
+    }
+}
+
+}  // namespace mi355

@@ -58,6 +58,30 @@ class ClassifierHead(nn.Module):
         return self.fc(x)
 
 
+def _swin_relative_position_index(ws: int) -> torch.Tensor:
+    """timm WindowAttention's ``relative_position_index`` buffer (kept only for state-dict fidelity: the HIP path
+    bakes the dense bias at pack time)."""
+    c = torch.stack(torch.meshgrid([torch.arange(ws), torch.arange(ws)], indexing="ij")).flatten(1)
+    rel = (c[:, :, None] - c[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    return rel.sum(-1)
+
+
+def _swin_attn_mask(res: int, ws: int, shift: int) -> torch.Tensor:
+    """timm SwinTransformerBlock's ``attn_mask`` buffer (0 / -100); the kernel derives it from region labels."""
+    img = torch.zeros((res, res))
+    cnt = 0
+    for h in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+        for w in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            img[h, w] = cnt
+            cnt += 1
+    mw = img.view(res // ws, ws, res // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws)
+    m = mw.unsqueeze(1) - mw.unsqueeze(2)
+    return m.masked_fill(m != 0, -100.0).masked_fill(m == 0, 0.0)
+
+
 def _table(handle):
     L = lib()
     out = []
@@ -129,11 +153,16 @@ class MI355Model(nn.Module):
         for name, t in list(self.named_parameters()) + list(self.named_buffers()):
             if t.dtype != torch.float32:
                 if name.endswith("relative_position_index"):
-                    continue
-                t.zero_()
+                    t.copy_(_swin_relative_position_index(int(round(t.shape[0] ** 0.5))))
+                else:
+                    t.zero_()
                 continue
             leaf = name.rsplit(".", 1)[-1]
-            if leaf == "running_var":
+            if leaf == "attn_mask":
+                ws = int(round(t.shape[1] ** 0.5))
+                res = int(round(t.shape[0] ** 0.5)) * ws
+                t.copy_(_swin_attn_mask(res, ws, ws // 2))
+            elif leaf == "running_var":
                 t.fill_(1.0)
             elif leaf in ("running_mean", "bias"):
                 t.zero_()

@@ -1,0 +1,71 @@
+"""swin_base_patch4_window7_224 (BASELINE configs[3]): HIP executor incl. the MFMA window-attention kernel vs the
+CPU oracle.  Backbone parity is UNPINNED against timm itself (see oracle/__init__.py)."""
+import pytest
+import torch
+
+import imageretrievalresearch_amd as M
+from oracle import swin
+from test_effnet_gpu import images, rel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL_TAP_SIM = 2e-2
+TOL_EMB_FP32 = 4e-2
+
+
+@pytest.fixture(scope="module")
+def setup():
+    sd = swin.init_state_dict(6)
+    model = M.create_model("swin_base_patch4_window7_224").to(DEV).eval()
+    model.load_state_dict(sd, strict=True)
+    return sd, model
+
+
+def test_swin_blocks_match_bf16_sim_oracle(setup):
+    sd, model = setup
+    x = torch.from_numpy(images(51, 2))
+    taps = {}
+    want = swin.forward_features(sd, x, sim_bf16=True, taps=taps)
+    model.enable_taps(True)
+    got = model.forward_features(x.to(DEV))
+    worst = ("", 0.0)
+    for name, ref in taps.items():
+        t = model.read_tap(name).cpu()                      # (B, C, h, w) view of the token tensor
+        t = t.flatten(2).transpose(1, 2)
+        assert t.shape == ref.shape, (name, t.shape, ref.shape)
+        e = rel(t, ref)
+        worst = max(worst, (name, e), key=lambda p: p[1])
+        print(f"tap {name:24s} rel L2 {e:.3e}")
+        assert e < TOL_TAP_SIM, f"tap {name}: rel L2 {e:.3e}"
+    model.enable_taps(False)
+    assert got.shape == (2, 1024)
+    assert rel(got.cpu(), want) < TOL_TAP_SIM
+    print("worst", worst)
+
+
+def test_swin_embedding_logits_and_head_identity(setup):
+    sd, model = setup
+    x = torch.from_numpy(images(53, 2))
+    f32 = swin.forward_features(sd, x)
+    emb = model.forward_features(x.to(DEV))
+    assert rel(emb.cpu(), f32) < TOL_EMB_FP32
+    assert torch.nn.functional.cosine_similarity(emb.cpu(), f32).min() > 0.999
+    out = model(x.to(DEV))
+    assert out.shape == (2, 1000)
+    assert rel(out.cpu(), swin.forward(sd, x, sim_bf16=True)) < 3e-2
+    assert torch.equal(out, model(x.to(DEV)))               # deterministic
+    model.head = torch.nn.Identity()                        # train/train_vit_triplet.py:357
+    e2 = model(x.to(DEV))
+    assert e2.shape == (2, 1024) and torch.equal(e2, emb)
+    model.head = torch.nn.Linear(1024, 1000).to(DEV)
+    with pytest.raises(M.MI355Error):
+        model(torch.zeros(1, 3, 192, 192, device=DEV))      # swin is fixed at 224x224
+
+
+def test_swin_state_dict_buffers_match_timm_definition():
+    m = M.create_model("swin_base_patch4_window7_224", num_classes=0)
+    sd = swin.init_state_dict(6, num_classes=0)
+    msd = m.state_dict()
+    for k in msd:
+        if k.endswith("relative_position_index") or k.endswith("attn_mask"):
+            assert torch.equal(msd[k].float(), sd[k].float()), k
