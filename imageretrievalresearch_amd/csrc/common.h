@@ -53,6 +53,16 @@ __device__ __forceinline__ float sigmoid_f(float x) {
 }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 
+// exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far below the bf16 rounding that
+// follows): rcp + exp2 + 5 FMAs instead of libm erff (~3x the instructions; 50 us per Swin fc1 epilogue).
+__device__ __forceinline__ float gelu_f(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const float e = 1.0f - poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // erf(|x|/sqrt2)
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
+
 // activation codes shared by the conv / GEMM epilogues
 enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_RELU6 = 3, ACT_GELU = 4, ACT_SIGMOID = 5 };
 
@@ -61,7 +71,7 @@ __device__ __forceinline__ float apply_act(float x, int act) {
         case ACT_SILU: return silu_f(x);
         case ACT_RELU: return fmaxf(x, 0.f);
         case ACT_RELU6: return fminf(fmaxf(x, 0.f), 6.f);
-        case ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+        case ACT_GELU: return gelu_f(x);
         case ACT_SIGMOID: return sigmoid_f(x);
         default: return x;
     }

@@ -244,6 +244,212 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(const GemmArgs g, const int n
     }
 }
 
+// =====================================================================================
+// Large-K path (K % 64 == 0, Swin's linears and the wide EfficientNet layers): 128 x 128 x 64 tiles, operands
+// streamed HBM -> LDS with global_load_lds (16 B per lane, no VGPR round trip), double-buffered so tile t+1
+// lands while tile t is multiplied.  The DMA writes LDS lane-linearly (8 rows x 128 B per wave instruction), so
+// the bank-conflict swizzle lives on the per-lane SOURCE address: physical 16-byte chunk = logical ^ ((row>>1)&7),
+// and the fragment reads apply the same XOR (cdna guide rule 21).  4 waves as 2(M) x 2(N), 64 x 64 per wave.
+// Rows past M / N are clamped to the last valid row (finite garbage, never stored), so no guards in the loop.
+// =====================================================================================
+constexpr int BG_BM = 128, BG_BN = 128, BG_BK = 64;
+
+__device__ __forceinline__ void glds16(const bf16_t* gsrc, bf16_t* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void k_gemm_big(const GemmArgs g, const int n_tiles, const int nwg) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t bsm[];
+    bf16_t* As = bsm;                              // [2][128*64]
+    bf16_t* Ws = bsm + 2 * BG_BM * BG_BK;          // [2][128*64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int logical;
+    {
+        const int bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int mb = logical / n_tiles, nb = logical - mb * n_tiles;
+    const int m0 = mb * BG_BM, n0 = nb * BG_BN;
+    const int Npad = (g.N + 15) & ~15;
+
+    // staging: wave w issues 4 A pieces and 4 W pieces per tile; piece p covers tile rows p*8 .. p*8+7
+    const bf16_t* a_src[4];
+    const bf16_t* w_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int lchunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int m = min(m0 + row, g.M - 1);
+        const int n = min(n0 + row, Npad - 1);
+        a_src[i] = g.A + (size_t)m * g.lda + lchunk * 8;
+        w_src[i] = g.W + (size_t)n * g.ldw + lchunk * 8;
+    }
+    auto stage = [&](int buf, int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave * 4 + i;            // wave-uniform
+            glds16(a_src[i] + k0, As + buf * BG_BM * BG_BK + piece * 512);
+            glds16(w_src[i] + k0, Ws + buf * BG_BN * BG_BK + piece * 512);
+        }
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    f32x4 acc[4][4];   // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nt = g.K / BG_BK;
+    stage(0, 0);
+    __syncthreads();   // the fence drains vmcnt for the LDS-DMA as well
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) stage(buf ^ 1, (t + 1) * BG_BK);
+        const bf16_t* as = As + buf * BG_BM * BG_BK;
+        const bf16_t* ws = Ws + buf * BG_BN * BG_BK;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ra = wm * 64 + i * 16 + fr;
+                const int rw = wn * 64 + i * 16 + fr;
+                af[i] = *reinterpret_cast<const bf16x8*>(&as[ra * 64 + (((ks * 4 + fq) ^ ((ra >> 1) & 7)) << 3)]);
+                wf[i] = *reinterpret_cast<const bf16x8*>(&ws[rw * 64 + (((ks * 4 + fq) ^ ((rw >> 1) & 7)) << 3)]);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        }
+        __syncthreads();   // next tile has landed (vmcnt(0)) and everyone is done reading this one
+    }
+
+    // epilogue (same contract as k_gemm_bf16): lane holds n = .. + fq*4 + r, m = .. + fr
+    const bool staged = (!g.out_f32) && (g.res == nullptr);
+    if (staged) {
+        constexpr int CLD = BG_BN + 8;
+        bf16_t* Cs = bsm;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int ml = wm * 64 + mi * 16 + fr;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int nl = wn * 64 + ni * 16 + fq * 4;
+                const int n = n0 + nl;
+                f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                if (n < Npad) b = *reinterpret_cast<const f32x4*>(g.bias + n);
+                u32x2 o;
+                o.x = pack2bf(apply_act(acc[ni][mi].x + b.x, g.act), apply_act(acc[ni][mi].y + b.y, g.act));
+                o.y = pack2bf(apply_act(acc[ni][mi].z + b.z, g.act), apply_act(acc[ni][mi].w + b.w, g.act));
+                *reinterpret_cast<u32x2*>(&Cs[ml * CLD + nl]) = o;
+            }
+        }
+        __syncthreads();
+        constexpr int CPR = BG_BN / 8;
+        for (int id = tid; id < BG_BM * CPR; id += 256) {
+            const int row = id / CPR, c = id - row * CPR;
+            const int m = m0 + row, n = n0 + c * 8;
+            if (m < g.M && n < g.N)
+                *reinterpret_cast<u32x4*>((bf16_t*)g.out + (size_t)m * g.ldo + n) =
+                    *reinterpret_cast<const u32x4*>(&Cs[row * CLD + c * 8]);
+        }
+        return;
+    }
+    if (!g.out_f32 && g.res_n >= g.N) {
+        // residual layers (Swin proj / fc2 update the stream in place): stage the fp32 tile so the add happens
+        // before the single bf16 rounding, then stream rows with 16-byte residual loads and stores.
+        constexpr int FLD = BG_BN + 4;
+        float* Cf = reinterpret_cast<float*>(bsm);   // [128][132] fp32 = 67.6 KB
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int ml = wm * 64 + mi * 16 + fr;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int nl = wn * 64 + ni * 16 + fq * 4;
+                const int n = n0 + nl;
+                f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                if (n < Npad) b = *reinterpret_cast<const f32x4*>(g.bias + n);
+                f32x4 o = {apply_act(acc[ni][mi].x + b.x, g.act), apply_act(acc[ni][mi].y + b.y, g.act),
+                           apply_act(acc[ni][mi].z + b.z, g.act), apply_act(acc[ni][mi].w + b.w, g.act)};
+                *reinterpret_cast<f32x4*>(&Cf[ml * FLD + nl]) = o;
+            }
+        }
+        __syncthreads();
+        constexpr int CPR = BG_BN / 8;
+        for (int id = tid; id < BG_BM * CPR; id += 256) {
+            const int row = id / CPR, c = id - row * CPR;
+            const int m = m0 + row, n = n0 + c * 8;
+            if (m < g.M && n < g.N) {
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(&Cf[row * FLD + c * 8]);
+                const f32x4 c1 = *reinterpret_cast<const f32x4*>(&Cf[row * FLD + c * 8 + 4]);
+                const u32x4 rr = *reinterpret_cast<const u32x4*>(g.res + (size_t)m * g.ldr + n);
+                u32x4 o;
+                o.x = pack2bf(c0.x + lo_bf(rr.x), c0.y + hi_bf(rr.x));
+                o.y = pack2bf(c0.z + lo_bf(rr.y), c0.w + hi_bf(rr.y));
+                o.z = pack2bf(c1.x + lo_bf(rr.z), c1.y + hi_bf(rr.z));
+                o.w = pack2bf(c1.z + lo_bf(rr.w), c1.w + hi_bf(rr.w));
+                *reinterpret_cast<u32x4*>((bf16_t*)g.out + (size_t)m * g.ldo + n) = o;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm * 64 + mi * 16 + fr;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 64 + ni * 16 + fq * 4;
+            if (n >= g.N) continue;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
+            float v[4] = {acc[ni][mi].x + b.x, acc[ni][mi].y + b.y, acc[ni][mi].z + b.z, acc[ni][mi].w + b.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (n + r < g.N) {
+                    float x = apply_act(v[r], g.act);
+                    if (g.res && n + r < g.res_n) x += bf2f(g.res[(size_t)m * g.ldr + n + r]);
+                    v[r] = x;
+                }
+            }
+            if (n + 3 < g.N && !g.out_f32) {
+                u32x2 o;
+                o.x = pack2bf(v[0], v[1]);
+                o.y = pack2bf(v[2], v[3]);
+                *reinterpret_cast<u32x2*>((bf16_t*)g.out + (size_t)m * g.ldo + n) = o;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (n + r < g.N) {
+                        if (g.out_f32) ((float*)g.out)[(size_t)m * g.ldo + n + r] = v[r];
+                        else ((bf16_t*)g.out)[(size_t)m * g.ldo + n + r] = f2bf(v[r]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+static int launch_big(const GemmArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)BG_BM * (BG_BN + 4) * 4;   // 67.6 KB: fp32 epilogue tile (>= the 64 KB of stage buffers)
+    static bool attr_done = false;
+    if (!attr_done) {
+        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const int n_tiles = cdiv(a.N, BG_BN), m_tiles = cdiv(a.M, BG_BM);
+    const long nwg = (long)n_tiles * m_tiles;
+    MI355_REQUIRE(nwg < (1l << 31), "gemm: grid too large");
+    hipLaunchKernelGGL(k_gemm_big, dim3((unsigned)nwg), dim3(256), lds, st, a, n_tiles, (int)nwg);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
 // Tile selection.  BN = 16*NT minimising padded columns (prefer fewer, larger tiles: fewer A-panel re-reads);
 // BM = 64 when a 128-row tiling would leave the 256 CUs with < 4 blocks each (late 14x14 / 7x7 layers are
 // latency-bound: more, smaller blocks overlap their load latency); BK = 64 once K >= 64.
@@ -303,6 +509,10 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t st) {
     // Measured on MI355X (profiles/r01_effnet_per_op_*.txt): the 64-row / BK=64 variants lose to 128 x BN x 32
     // on every EfficientNet layer (each wave re-reads the whole W tile from LDS, so halving the rows per wave
     // makes the block LDS-bound); they stay instantiated for tiny-M problems (classifier, M = batch).
+    // compute-heavy shapes: DMA-staged 128x128x64 kernel (no gate / ReLU6 prologue there)
+    if (a.K % 64 == 0 && a.K >= 128 && a.N >= 96 && a.M >= 1024 && !a.gate && !a.a_relu6 && a.ldw >= a.K &&
+        ((uintptr_t)a.A % 16 == 0) && a.lda % 8 == 0)
+        return launch_big(a, st);
     const int nt = pick_nt(a.N);
     if (a.M <= 64) return a.K >= 64 ? launch_nt<1, 64>(a, nt, st) : launch_nt<1, 32>(a, nt, st);
     return launch_nt<2, 32>(a, nt, st);
