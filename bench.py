@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--microbatch", type=int, default=int(os.environ.get("MI355_MICROBATCH", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="efficientnet_b3a")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     return ap.parse_args()
 
 
@@ -85,10 +87,15 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         a.gpus = world
     dist = torch.distributed
+    if a.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
 
     # ---- resident inputs (timed region starts with everything in HBM)
     model = M.create_model(a.model, num_classes=0, seed=0).to(dev).eval()
