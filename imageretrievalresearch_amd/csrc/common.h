@@ -77,6 +77,29 @@ __device__ __forceinline__ float apply_act(float x, int act) {
     }
 }
 
+// Compile-time activation.  A runtime `switch (act)` inside an unrolled epilogue is expanded per value: the
+// NT=12 GEMM had 2813 scalar branches and 24k instructions (196 KB of code, far beyond the instruction cache) and
+// its epilogue ran at 2.2 TB/s where plain stores do 6 TB/s.  MI355_ACT_DISPATCH hoists the switch out once and
+// compiles BODY straight-line for the common activations (ACT is a constexpr int inside BODY).
+template <int ACT>
+__device__ __forceinline__ float act_c(float x) {
+    if constexpr (ACT == ACT_SILU) return silu_f(x);
+    else if constexpr (ACT == ACT_RELU) return fmaxf(x, 0.f);
+    else if constexpr (ACT == ACT_RELU6) return fminf(fmaxf(x, 0.f), 6.f);
+    else if constexpr (ACT == ACT_GELU) return gelu_f(x);
+    else if constexpr (ACT == ACT_SIGMOID) return sigmoid_f(x);
+    else return x;
+}
+#define MI355_ACT_DISPATCH(act_runtime, ...)                                      \
+    switch (act_runtime) {                                                        \
+        case ::mi355::ACT_SILU: { constexpr int ACT = ::mi355::ACT_SILU; __VA_ARGS__ } break;   \
+        case ::mi355::ACT_GELU: { constexpr int ACT = ::mi355::ACT_GELU; __VA_ARGS__ } break;   \
+        case ::mi355::ACT_RELU6: { constexpr int ACT = ::mi355::ACT_RELU6; __VA_ARGS__ } break; \
+        case ::mi355::ACT_RELU: { constexpr int ACT = ::mi355::ACT_RELU; __VA_ARGS__ } break;   \
+        case ::mi355::ACT_SIGMOID: { constexpr int ACT = ::mi355::ACT_SIGMOID; __VA_ARGS__ } break; \
+        default: { constexpr int ACT = ::mi355::ACT_NONE; __VA_ARGS__ } break;    \
+    }
+
 // wave64 reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -63,8 +63,10 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
             acc[0] += p[t] * w0.x; acc[1] += p[t] * w0.y; acc[2] += p[t] * w0.z; acc[3] += p[t] * w0.w;
             acc[4] += p[t] * w1.x; acc[5] += p[t] * w1.y; acc[6] += p[t] * w1.z; acc[7] += p[t] * w1.w;
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = apply_act(acc[j], act);
+        MI355_ACT_DISPATCH(act, {
+_Pragma("unroll")
+            for (int j = 0; j < 8; ++j) acc[j] = act_c<ACT>(acc[j]);
+        })
         *reinterpret_cast<u32x4*>(o + c0) = pack8(acc);
     }
 }
@@ -161,14 +163,17 @@ __global__ __launch_bounds__(256) void k_dwconv(const bf16_t* __restrict__ in, c
             }
         }
         bf16_t* o = out + (((size_t)b * Ho + oy) * Wo + ox0) * C + c0;
+        MI355_ACT_DISPATCH(act, {
+_Pragma("unroll")
+            for (int p = 0; p < DW_PX; ++p)
+_Pragma("unroll")
+                for (int j = 0; j < 8; ++j) acc[p][j] = act_c<ACT>(acc[p][j]);
+        })
 #pragma unroll
         for (int p = 0; p < DW_PX; ++p) {
             if (ox0 + p < Wo) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    acc[p][j] = apply_act(acc[p][j], act);
-                    psum[j] += acc[p][j];
-                }
+                for (int j = 0; j < 8; ++j) psum[j] += acc[p][j];
                 *reinterpret_cast<u32x4*>(o + (size_t)p * C) = pack8(acc[p]);
             }
         }

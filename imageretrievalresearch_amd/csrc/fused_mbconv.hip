@@ -121,6 +121,19 @@ __global__ __launch_bounds__(FL_THREADS) void k_fused_late(const FusedArgs a) {
                     }
                 }
             }
+            MI355_ACT_DISPATCH(a.act_e, {
+_Pragma("unroll")
+                for (int j = 0; j < NIW; ++j) {
+                    const int n = cbase + (wave * NIW + j) * 16 + (lane >> 4) * 4;
+                    f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+                    if (n < midp) bb = *reinterpret_cast<const f32x4*>(a.be + n);
+_Pragma("unroll")
+                    for (int m = 0; m < MTP; ++m) {
+                        acc[j][m].x = act_c<ACT>(acc[j][m].x + bb.x); acc[j][m].y = act_c<ACT>(acc[j][m].y + bb.y);
+                        acc[j][m].z = act_c<ACT>(acc[j][m].z + bb.z); acc[j][m].w = act_c<ACT>(acc[j][m].w + bb.w);
+                    }
+                }
+            })
 #pragma unroll
             for (int m = 0; m < MTP; ++m) {
                 const int p = (mb + m) * 16 + fr;          // this lane's pixel
@@ -130,12 +143,9 @@ __global__ __launch_bounds__(FL_THREADS) void k_fused_late(const FusedArgs a) {
 #pragma unroll
                     for (int j = 0; j < NIW; ++j) {
                         const int nl = (wave * NIW + j) * 16 + (lane >> 4) * 4;   // channel within the slab
-                        const int n = cbase + nl;
-                        f32x4 bb = {0.f, 0.f, 0.f, 0.f};
-                        if (n < midp) bb = *reinterpret_cast<const f32x4*>(a.be + n);
                         u32x2 o;
-                        o.x = pack2bf(apply_act(acc[j][m].x + bb.x, a.act_e), apply_act(acc[j][m].y + bb.y, a.act_e));
-                        o.y = pack2bf(apply_act(acc[j][m].z + bb.z, a.act_e), apply_act(acc[j][m].w + bb.w, a.act_e));
+                        o.x = pack2bf(acc[j][m].x, acc[j][m].y);
+                        o.y = pack2bf(acc[j][m].z, acc[j][m].w);
                         *reinterpret_cast<u32x2*>(&Es[(size_t)erow * ELD + nl]) = o;
                     }
                 }
@@ -190,14 +200,17 @@ __global__ __launch_bounds__(FL_THREADS) void k_fused_late(const FusedArgs a) {
                 }
             }
             bf16_t* o = a.D + (((size_t)b * a.Ho + oy) * a.Wo + ox0) * a.mid + c0;
+            MI355_ACT_DISPATCH(a.act_d, {
+_Pragma("unroll")
+                for (int p = 0; p < PX; ++p)
+_Pragma("unroll")
+                    for (int j = 0; j < 8; ++j) acc[p][j] = act_c<ACT>(acc[p][j]);
+            })
 #pragma unroll
             for (int p = 0; p < PX; ++p) {
                 if (ox0 + p < a.Wo) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        acc[p][j] = apply_act(acc[p][j], a.act_d);
-                        psum[j] += acc[p][j];
-                    }
+                    for (int j = 0; j < 8; ++j) psum[j] += acc[p][j];
                     u32x4 ov;
                     ov.x = pack2bf(acc[p][0], acc[p][1]); ov.y = pack2bf(acc[p][2], acc[p][3]);
                     ov.z = pack2bf(acc[p][4], acc[p][5]); ov.w = pack2bf(acc[p][6], acc[p][7]);
@@ -222,6 +235,259 @@ __global__ __launch_bounds__(FL_THREADS) void k_fused_late(const FusedArgs a) {
         }
         __syncthreads();   // Es / red are rewritten by the next slab
     }
+}
+
+// =====================================================================================
+// Band variant for the early stages (28x28 .. 112x112, Cin <= 64): a workgroup owns TH output rows of one image
+// (full width) plus the KS-S halo rows above/below, recomputes the expand GEMM for the halo (cheap: K <= 64), and
+// walks the expanded channels in slabs of 64.  Here the waves split the PIXELS (each wave sweeps 16-pixel
+// sub-tiles with the slab's W fragments held in registers); phase 2 is the same depthwise as above.
+// The SE squeeze becomes one partial sum per (image, band): pool[b][band][mid].
+// =====================================================================================
+template <int KS, int S, int KST, int PX>
+__global__ __launch_bounds__(FL_THREADS) void k_fused_band(const FusedArgs a) {
+    constexpr int MC = 64, NT = 4;
+    constexpr int PAD = KS / 2;
+    constexpr int IW = (PX - 1) * S + KS;
+    constexpr int CGC = MC / 8;
+    constexpr int Kp = 32 * KST, XLD = Kp + 8, ELD = MC + 8;
+    extern __shared__ __attribute__((aligned(16))) bf16_t fsm[];
+    const int band = blockIdx.x, b = blockIdx.y;
+    const int oy0 = band * a.TH;
+    const int th = min(a.TH, a.Ho - oy0);
+    const int IH = (a.TH - 1) * S + KS;
+    const int iy0 = oy0 * S - PAD;
+    const int P = IH * a.W;
+    const int MT = (P + 15) >> 4;
+    const int EW = a.W + 2 * PAD;
+    const int EP = IH * EW + IW;
+    bf16_t* Xs = fsm;
+    bf16_t* Es = fsm + (size_t)MT * 16 * XLD;
+    float* red = reinterpret_cast<float*>(Es + (size_t)((EP + 7) & ~7) * ELD);   // [FL_THREADS][8]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        constexpr int kc = Kp >> 3;
+        const bf16_t* xb = a.X + (size_t)b * a.H * a.W * a.Cin;
+        for (int id = tid; id < MT * 16 * kc; id += FL_THREADS) {
+            const int row = id / kc, c = id - row * kc;
+            const int r = row / a.W, x = row - r * a.W;
+            const int iy = iy0 + r;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (row < P && iy >= 0 && iy < a.H && c * 8 < a.Cin)
+                v = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * a.W + x) * a.Cin + c * 8);
+            *reinterpret_cast<u32x4*>(&Xs[row * XLD + c * 8]) = v;
+        }
+        for (int id = tid; id < EP * (ELD / 8); id += FL_THREADS)
+            *reinterpret_cast<u32x4*>(&Es[(size_t)id * 8]) = (u32x4){0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
+
+    const int fr = lane & 15, fq = lane >> 4, fk = fq * 8;
+    const int midp = (a.mid + 15) & ~15;
+    const int strips = (a.Wo + PX - 1) / PX;
+    const int nitems = CGC * strips * th;
+    const int nchunks = (a.mid + MC - 1) / MC;
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int cbase = chunk * MC;
+        // ---- phase 1: waves split the pixel sub-tiles; the slab's W fragments + bias live in registers
+        {
+            bf16x8 wf[NT][KST];
+            f32x4 bb[NT];
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                const int n = cbase + ni * 16 + fr;
+#pragma unroll
+                for (int ks = 0; ks < KST; ++ks) {
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (n < midp) v = *reinterpret_cast<const u32x4*>(a.We + (size_t)n * a.Kp + ks * 32 + fk);
+                    wf[ni][ks] = *reinterpret_cast<bf16x8*>(&v);
+                }
+                const int n4 = cbase + ni * 16 + fq * 4;
+                bb[ni] = n4 < midp ? *reinterpret_cast<const f32x4*>(a.be + n4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            for (int mt = wave; mt < MT; mt += FL_THREADS / 64) {
+                bf16x8 af[KST];
+#pragma unroll
+                for (int ks = 0; ks < KST; ++ks)
+                    af[ks] = *reinterpret_cast<const bf16x8*>(&Xs[(mt * 16 + fr) * XLD + ks * 32 + fk]);
+                f32x4 acc[NT];
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) {
+                    acc[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KST; ++ks)
+                        acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni][ks], af[ks], acc[ni], 0, 0, 0);
+                }
+                MI355_ACT_DISPATCH(a.act_e, {
+_Pragma("unroll")
+                    for (int ni = 0; ni < NT; ++ni) {
+                        acc[ni].x = act_c<ACT>(acc[ni].x + bb[ni].x); acc[ni].y = act_c<ACT>(acc[ni].y + bb[ni].y);
+                        acc[ni].z = act_c<ACT>(acc[ni].z + bb[ni].z); acc[ni].w = act_c<ACT>(acc[ni].w + bb[ni].w);
+                    }
+                })
+                const int p = mt * 16 + fr;
+                if (p < P) {
+                    const int r = p / a.W;
+                    const int erow = r * EW + (p - r * a.W) + PAD;
+#pragma unroll
+                    for (int ni = 0; ni < NT; ++ni) {
+                        u32x2 o;
+                        o.x = pack2bf(acc[ni].x, acc[ni].y);
+                        o.y = pack2bf(acc[ni].z, acc[ni].w);
+                        *reinterpret_cast<u32x2*>(&Es[(size_t)erow * ELD + ni * 16 + fq * 4]) = o;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 2: depthwise from the LDS slab (rows outside the image are skipped, x is zero padded)
+        float psum[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) psum[j] = 0.f;
+        const int my_cg = tid % CGC;
+        const int c0 = cbase + my_cg * 8;
+        const bool cok = c0 < a.mid;
+        for (int item = tid; item < nitems; item += FL_THREADS) {
+            const int rest = item / CGC;
+            const int sx = rest % strips, oy = oy0 + rest / strips;
+            const int ox0 = sx * PX;
+            if (!cok) continue;
+            float acc[PX][8];
+            {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bd + c0);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.bd + c0 + 4);
+#pragma unroll
+                for (int p = 0; p < PX; ++p) {
+                    acc[p][0] = b0.x; acc[p][1] = b0.y; acc[p][2] = b0.z; acc[p][3] = b0.w;
+                    acc[p][4] = b1.x; acc[p][5] = b1.y; acc[p][6] = b1.z; acc[p][7] = b1.w;
+                }
+            }
+#pragma unroll 1
+            for (int ky = 0; ky < KS; ++ky) {
+                const int iy = oy * S - PAD + ky;
+                if (iy < 0 || iy >= a.H) continue;
+                float wk[KS][8];
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx)
+                    fl_unpack8(*reinterpret_cast<const u32x4*>(a.Wd + (size_t)(ky * KS + kx) * a.mid + c0), wk[kx]);
+                const bf16_t* erow = Es + (size_t)((iy - iy0) * EW + ox0 * S) * ELD + my_cg * 8;
+#pragma unroll
+                for (int i = 0; i < IW; ++i) {
+                    float v[8];
+                    fl_unpack8(*reinterpret_cast<const u32x4*>(erow + (size_t)i * ELD), v);
+#pragma unroll
+                    for (int p = 0; p < PX; ++p) {
+                        const int kx = i - p * S;
+                        if (kx >= 0 && kx < KS) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[p][j] += wk[kx][j] * v[j];
+                        }
+                    }
+                }
+            }
+            bf16_t* o = a.D + (((size_t)b * a.Ho + oy) * a.Wo + ox0) * a.mid + c0;
+            MI355_ACT_DISPATCH(a.act_d, {
+_Pragma("unroll")
+                for (int p = 0; p < PX; ++p)
+_Pragma("unroll")
+                    for (int j = 0; j < 8; ++j) acc[p][j] = act_c<ACT>(acc[p][j]);
+            })
+#pragma unroll
+            for (int p = 0; p < PX; ++p) {
+                if (ox0 + p < a.Wo) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) psum[j] += acc[p][j];
+                    u32x4 ov;
+                    ov.x = pack2bf(acc[p][0], acc[p][1]); ov.y = pack2bf(acc[p][2], acc[p][3]);
+                    ov.z = pack2bf(acc[p][4], acc[p][5]); ov.w = pack2bf(acc[p][6], acc[p][7]);
+                    *reinterpret_cast<u32x4*>(o + (size_t)p * a.mid) = ov;
+                }
+            }
+        }
+        if (a.pool != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[tid * 8 + j] = psum[j];
+            __syncthreads();
+            // two fixed-order stages: 8 threads per channel group add 8 entries each, then one thread adds the 8 parts
+            float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (tid < 64) {
+                const int cg = tid & 7, part = tid >> 3;
+                for (int j2 = 0; j2 < 8; ++j2) {
+                    const int u = cg + CGC * (part * 8 + j2);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s[j] += red[u * 8 + j];
+                }
+            }
+            __syncthreads();
+            if (tid < 64) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) red[tid * 8 + j] = s[j];
+            }
+            __syncthreads();
+            if (tid < CGC && cbase + tid * 8 < a.mid) {
+                float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int part = 0; part < 8; ++part)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t[j] += red[(part * 8 + tid) * 8 + j];
+                float* pp = a.pool + ((size_t)b * gridDim.x + band) * a.mid + cbase + tid * 8;
+                *reinterpret_cast<f32x4*>(pp) = (f32x4){t[0], t[1], t[2], t[3]};
+                *reinterpret_cast<f32x4*>(pp + 4) = (f32x4){t[4], t[5], t[6], t[7]};
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static size_t band_lds_bytes(int W, int Kp, int k, int stride, int TH, int px) {
+    const int pad = k / 2, IH = (TH - 1) * stride + k;
+    const int P = IH * W, MT = (P + 15) / 16, iw = (px - 1) * stride + k;
+    const int EP = IH * (W + 2 * pad) + iw;
+    return (size_t)MT * 16 * (Kp + 8) * 2 + (size_t)((EP + 7) & ~7) * 72 * 2 + FL_THREADS * 8 * 4;
+}
+
+// Largest band height (output rows) whose LDS image fits; 0 = unsupported.
+int fused_band_rows(int H, int W, int Cin, int mid, int k, int stride) {
+    if (Cin % 8 || mid % 8 || Cin > 64 || W > 128) return 0;
+    if (!((k == 3 || k == 5) && (stride == 1 || stride == 2))) return 0;
+    const int Kp = (Cin + 31) & ~31, pad = k / 2;
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    const int px = Wo % 7 == 0 ? 7 : 4;
+    int best = 0;
+    for (int th = 1; th <= Ho && th <= 16; ++th)
+        if (band_lds_bytes(W, Kp, k, stride, th, px) <= 158 * 1024) best = th;
+    return best;
+}
+
+template <int KS, int S, int KST, int PX>
+static int launch_fb(const FusedArgs& a, int B, hipStream_t st) {
+    const size_t lds = band_lds_bytes(a.W, a.Kp, KS, S, a.TH, PX);
+    static bool attr_done = false;
+    if (!attr_done) {
+        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_fused_band<KS, S, KST, PX>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_fused_band<KS, S, KST, PX>), dim3(cdiv(a.Ho, a.TH), B), dim3(FL_THREADS), lds, st, a);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
+template <int KS, int S>
+static int launch_fb_ks(const FusedArgs& a, int B, hipStream_t st) {
+    const bool px7 = (a.Wo % 7 == 0);
+    if (a.Kp == 32) return px7 ? launch_fb<KS, S, 1, 7>(a, B, st) : launch_fb<KS, S, 1, 4>(a, B, st);
+    return px7 ? launch_fb<KS, S, 2, 7>(a, B, st) : launch_fb<KS, S, 2, 4>(a, B, st);
+}
+
+int launch_fused_band(const FusedArgs& a, int B, int k, int stride, hipStream_t st) {
+    MI355_REQUIRE(a.TH >= 1 && (a.Kp == 32 || a.Kp == 64), "fused_band: unsupported shape");
+    if (k == 3 && stride == 1) return launch_fb_ks<3, 1>(a, B, st);
+    if (k == 3 && stride == 2) return launch_fb_ks<3, 2>(a, B, st);
+    if (k == 5 && stride == 1) return launch_fb_ks<5, 1>(a, B, st);
+    return launch_fb_ks<5, 2>(a, B, st);
 }
 
 static size_t fused_lds_bytes(int H, int W, int Kp, int MC, int k, int stride) {

@@ -10,6 +10,8 @@
 // register-staged prefetch (issue tile t+1 loads, compute tile t, write tile t+1, one barrier).
 #include "ops.h"
 
+#include <stdlib.h>
+
 namespace mi355 {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -69,6 +71,7 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(const GemmArgs g, const int n
         const int bid = blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        if (g.no_remap & 1) logical = bid;
     }
     const int mb = logical / n_tiles, nb = logical - mb * n_tiles;
     const int m0 = mb * BM;
@@ -131,9 +134,8 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(const GemmArgs g, const int n
 #pragma unroll
         for (int j = 0; j < WM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nt = (g.K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
+    const int nt = (g.no_remap & 4) ? 0 : (g.K + BK - 1) / BK;
+    if (nt) { load_tile(0); store_tile(0); }
     __syncthreads();
 
     const int fr = lane & 15;          // fragment row (n for W, m for A)
@@ -170,6 +172,22 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(const GemmArgs g, const int n
         __syncthreads();
     }
 
+    if (g.no_remap & 2) { if (acc[0][0].x == 12345.f) ((float*)g.out)[0] = 1.f; return; }
+    // bias + activation once, straight-line per activation (see MI355_ACT_DISPATCH); the store paths below only
+    // pack / add the residual / write.
+    MI355_ACT_DISPATCH(g.act, {
+_Pragma("unroll")
+        for (int ni = 0; ni < NT; ++ni) {
+            const int n = n0 + ni * 16 + (lane >> 4) * 4;
+            f32x4 b = {0.f, 0.f, 0.f, 0.f};
+            if (n < Npad) b = *reinterpret_cast<const f32x4*>(g.bias + n);
+_Pragma("unroll")
+            for (int mi = 0; mi < WM; ++mi) {
+                acc[ni][mi].x = act_c<ACT>(acc[ni][mi].x + b.x); acc[ni][mi].y = act_c<ACT>(acc[ni][mi].y + b.y);
+                acc[ni][mi].z = act_c<ACT>(acc[ni][mi].z + b.z); acc[ni][mi].w = act_c<ACT>(acc[ni][mi].w + b.w);
+            }
+        }
+    })
     // epilogue: D[row = n][col = m]; lane holds n = nbase + (lane>>4)*4 + r (r = 0..3), m = lane & 15.
     const bool staged = (!g.out_f32) && (g.res == nullptr);
     if (staged) {
@@ -181,12 +199,9 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(const GemmArgs g, const int n
 #pragma unroll
             for (int ni = 0; ni < NT; ++ni) {
                 const int nl = ni * 16 + (lane >> 4) * 4;
-                const int n = n0 + nl;
-                f32x4 b = {0.f, 0.f, 0.f, 0.f};
-                if (n < Npad) b = *reinterpret_cast<const f32x4*>(g.bias + n);
                 u32x2 o;
-                o.x = pack2bf(apply_act(acc[ni][mi].x + b.x, g.act), apply_act(acc[ni][mi].y + b.y, g.act));
-                o.y = pack2bf(apply_act(acc[ni][mi].z + b.z, g.act), apply_act(acc[ni][mi].w + b.w, g.act));
+                o.x = pack2bf(acc[ni][mi].x, acc[ni][mi].y);
+                o.y = pack2bf(acc[ni][mi].z, acc[ni][mi].w);
                 *reinterpret_cast<u32x2*>(&Cs[ml * CLD + nl]) = o;
             }
         }
@@ -209,10 +224,7 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(const GemmArgs g, const int n
         for (int ni = 0; ni < NT; ++ni) {
             const int n = n0 + ni * 16 + (lane >> 4) * 4;
             if (n >= g.N) continue;
-            const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);  // bias is padded to Npad
-            float v[4] = {acc[ni][mi].x + b.x, acc[ni][mi].y + b.y, acc[ni][mi].z + b.z, acc[ni][mi].w + b.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], g.act);
+            float v[4] = {acc[ni][mi].x, acc[ni][mi].y, acc[ni][mi].z, acc[ni][mi].w};
             const bool res_vec = g.res && (n + 3 < g.res_n);
             const bool res_part = g.res && !res_vec && (n < g.res_n);
             if (n + 3 < g.N && !res_part) {
@@ -331,6 +343,19 @@ __global__ __launch_bounds__(256) void k_gemm_big(const GemmArgs g, const int n_
     }
 
     // epilogue (same contract as k_gemm_bf16): lane holds n = .. + fq*4 + r, m = .. + fr
+    MI355_ACT_DISPATCH(g.act, {
+_Pragma("unroll")
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wn * 64 + ni * 16 + fq * 4;
+            f32x4 b = {0.f, 0.f, 0.f, 0.f};
+            if (n < Npad) b = *reinterpret_cast<const f32x4*>(g.bias + n);
+_Pragma("unroll")
+            for (int mi = 0; mi < 4; ++mi) {
+                acc[ni][mi].x = act_c<ACT>(acc[ni][mi].x + b.x); acc[ni][mi].y = act_c<ACT>(acc[ni][mi].y + b.y);
+                acc[ni][mi].z = act_c<ACT>(acc[ni][mi].z + b.z); acc[ni][mi].w = act_c<ACT>(acc[ni][mi].w + b.w);
+            }
+        }
+    })
     const bool staged = (!g.out_f32) && (g.res == nullptr);
     if (staged) {
         constexpr int CLD = BG_BN + 8;
@@ -341,12 +366,9 @@ __global__ __launch_bounds__(256) void k_gemm_big(const GemmArgs g, const int n_
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 const int nl = wn * 64 + ni * 16 + fq * 4;
-                const int n = n0 + nl;
-                f32x4 b = {0.f, 0.f, 0.f, 0.f};
-                if (n < Npad) b = *reinterpret_cast<const f32x4*>(g.bias + n);
                 u32x2 o;
-                o.x = pack2bf(apply_act(acc[ni][mi].x + b.x, g.act), apply_act(acc[ni][mi].y + b.y, g.act));
-                o.y = pack2bf(apply_act(acc[ni][mi].z + b.z, g.act), apply_act(acc[ni][mi].w + b.w, g.act));
+                o.x = pack2bf(acc[ni][mi].x, acc[ni][mi].y);
+                o.y = pack2bf(acc[ni][mi].z, acc[ni][mi].w);
                 *reinterpret_cast<u32x2*>(&Cs[ml * CLD + nl]) = o;
             }
         }
@@ -372,12 +394,7 @@ __global__ __launch_bounds__(256) void k_gemm_big(const GemmArgs g, const int n_
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 const int nl = wn * 64 + ni * 16 + fq * 4;
-                const int n = n0 + nl;
-                f32x4 b = {0.f, 0.f, 0.f, 0.f};
-                if (n < Npad) b = *reinterpret_cast<const f32x4*>(g.bias + n);
-                f32x4 o = {apply_act(acc[ni][mi].x + b.x, g.act), apply_act(acc[ni][mi].y + b.y, g.act),
-                           apply_act(acc[ni][mi].z + b.z, g.act), apply_act(acc[ni][mi].w + b.w, g.act)};
-                *reinterpret_cast<f32x4*>(&Cf[ml * FLD + nl]) = o;
+                *reinterpret_cast<f32x4*>(&Cf[ml * FLD + nl]) = acc[ni][mi];
             }
         }
         __syncthreads();
@@ -407,12 +424,11 @@ __global__ __launch_bounds__(256) void k_gemm_big(const GemmArgs g, const int n_
         for (int ni = 0; ni < 4; ++ni) {
             const int n = n0 + wn * 64 + ni * 16 + fq * 4;
             if (n >= g.N) continue;
-            const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + n);
-            float v[4] = {acc[ni][mi].x + b.x, acc[ni][mi].y + b.y, acc[ni][mi].z + b.z, acc[ni][mi].w + b.w};
+            float v[4] = {acc[ni][mi].x, acc[ni][mi].y, acc[ni][mi].z, acc[ni][mi].w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (n + r < g.N) {
-                    float x = apply_act(v[r], g.act);
+                    float x = v[r];
                     if (g.res && n + r < g.res_n) x += bf2f(g.res[(size_t)m * g.ldr + n + r]);
                     v[r] = x;
                 }
@@ -453,11 +469,12 @@ static int launch_big(const GemmArgs& a, hipStream_t st) {
 // Tile selection.  BN = 16*NT minimising padded columns (prefer fewer, larger tiles: fewer A-panel re-reads);
 // BM = 64 when a 128-row tiling would leave the 256 CUs with < 4 blocks each (late 14x14 / 7x7 layers are
 // latency-bound: more, smaller blocks overlap their load latency); BK = 64 once K >= 64.
-static int pick_nt(int N) {
+static int pick_nt(int N, int max_nt = 12) {
     static const int opts[] = {2, 3, 4, 6, 8, 9, 12};
     int best = 2;
     double best_cost = 1e30;
     for (int nt : opts) {
+        if (nt > max_nt) continue;
         const int bn = nt * 16;
         const int tiles = (N + bn - 1) / bn;
         const double cost = (double)tiles * bn * (1.0 + 24.0 / bn) + 8.0 * tiles;
@@ -513,7 +530,11 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t st) {
     if (a.K % 64 == 0 && a.K >= 128 && a.N >= 96 && a.M >= 1024 && !a.gate && !a.a_relu6 && a.ldw >= a.K &&
         ((uintptr_t)a.A % 16 == 0) && a.lda % 8 == 0)
         return launch_big(a, st);
-    const int nt = pick_nt(a.N);
+    // small-K layers are pure streaming (one or two K tiles): narrower tiles keep 4+ waves per SIMD resident
+    static const int no_remap = getenv("MI355_NO_REMAP") ? atoi(getenv("MI355_NO_REMAP")) : 0;
+    const_cast<GemmArgs&>(a).no_remap = no_remap;
+    static const int small_k_nt = getenv("MI355_SMALLK_NT") ? atoi(getenv("MI355_SMALLK_NT")) : 12;
+    const int nt = pick_nt(a.N, a.K <= 64 ? small_k_nt : 12);
     if (a.M <= 64) return a.K >= 64 ? launch_nt<1, 64>(a, nt, st) : launch_nt<1, 32>(a, nt, st);
     return launch_nt<2, 32>(a, nt, st);
 }

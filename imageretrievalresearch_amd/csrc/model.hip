@@ -143,7 +143,8 @@ static size_t plan_slots(mi355_model* m, int nb, int H, int W) {
                 const int ho = conv_out(S[op.in].h, op.k, op.stride), wo = conv_out(S[op.in].w, op.k, op.stride);
                 S[op.out].h = ho; S[op.out].w = wo; S[op.out].c = op.cout;
                 need(op.out, (size_t)nb * ho * wo * op.cout * 2);
-                if (op.pool) need(SLOT_POOLPART, (size_t)nb * dw_pool_blocks(ho, wo, op.cout) * op.cout * 4);
+                // squeeze partials: per 256-item block (k_dwconv) or per row band (fused kernels, <= ho bands)
+                if (op.pool) need(SLOT_POOLPART, (size_t)nb * std::max(dw_pool_blocks(ho, wo, op.cout), ho) * op.cout * 4);
                 break;
             }
             case OP_SE:
@@ -263,7 +264,8 @@ static bool can_fuse(const mi355_model* m, size_t i, int h, int w) {
     const Op& d = m->def.ops[i + 1];
     if (g.kind != OP_GEMM || d.kind != OP_DW || g.out != SLOT_E || d.in != SLOT_E) return false;
     if (g.use_gate || g.res != SLOT_NONE || g.a_relu6 || !g.tap.empty()) return false;
-    return fused_late_supported(h, w, g.cin, g.cout, d.k, d.stride);
+    return fused_late_supported(h, w, g.cin, g.cout, d.k, d.stride) ||
+           (m->fuse_band && fused_band_rows(h, w, g.cin, g.cout, d.k, d.stride) > 0);
 }
 
 static int exec_fused(ExecCtx& cx, const Op& g, const Op& d) {
@@ -278,8 +280,13 @@ static int exec_fused(ExecCtx& cx, const Op& g, const Op& d) {
     a.H = S[g.in].h; a.W = S[g.in].w; a.Cin = g.cin; a.Kp = (g.cin + 31) & ~31; a.mid = g.cout;
     a.Ho = S[d.out].h; a.Wo = S[d.out].w; a.act_e = g.act; a.act_d = d.act;
     a.debug_skip = m->fuse_debug;
-    m->pool_nblk = 1;
-    return launch_fused_late(a, cx.nb, d.k, d.stride, cx.st);
+    if (fused_late_supported(a.H, a.W, g.cin, g.cout, d.k, d.stride)) {
+        m->pool_nblk = 1;
+        return launch_fused_late(a, cx.nb, d.k, d.stride, cx.st);
+    }
+    a.TH = fused_band_rows(a.H, a.W, g.cin, g.cout, d.k, d.stride);
+    m->pool_nblk = cdiv(a.Ho, a.TH);
+    return launch_fused_band(a, cx.nb, d.k, d.stride, cx.st);
 }
 
 static int run_backbone(ExecCtx& cx) {
@@ -517,6 +524,7 @@ int mi355_model_set_option(mi355_model_t m, const char* key, int64_t value) {
     const std::string k = key;
     if (k == "microbatch") m->microbatch = (int)value;
     else if (k == "fuse") m->fuse = value != 0;
+    else if (k == "fuse_band") m->fuse_band = value != 0;
     else if (k == "fuse_debug") m->fuse_debug = (int)value;
     else if (k == "profile") {
         m->profile = value != 0;

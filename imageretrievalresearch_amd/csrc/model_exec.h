@@ -51,6 +51,7 @@ struct mi355_model {
     size_t arena_bytes = 0;
     SlotState slots[SLOT_COUNT];
     int microbatch = 0;
+    bool fuse_band = false;     // band variant for the early stages: measured slower than the unfused pair (option "fuse_band")
     bool fuse = true;           // fused expand+depthwise for whole-image tiles (option "fuse")
     int fuse_debug = 0;
     int pool_nblk = 0;          // squeeze partials per image produced by the last depthwise stage

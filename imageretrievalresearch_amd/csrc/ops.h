@@ -20,6 +20,7 @@ struct GemmArgs {
     int M, N, K;
     int act;
     int a_relu6;
+    int no_remap;   // diagnosis: 1 = plain blockIdx tile order (no XCD-aware remap)
 };
 int launch_gemm_bf16(const GemmArgs& a, hipStream_t st);
 
@@ -34,10 +35,13 @@ struct FusedArgs {
     float* pool;          // optional [B][mid]: complete per-channel sums of D (SE squeeze, nblk = 1)
     int H, W, Cin, Kp, mid, Ho, Wo;
     int act_e, act_d;
+    int TH;               // band variant: output rows per workgroup (pool is then [B][ceil(Ho/TH)][mid])
     int debug_skip;       // diagnosis only: bit0 skip the expand GEMM phase, bit1 skip the depthwise phase
 };
 bool fused_late_supported(int H, int W, int Cin, int mid, int k, int stride);
 int launch_fused_late(const FusedArgs& a, int B, int k, int stride, hipStream_t st);
+int fused_band_rows(int H, int W, int Cin, int mid, int k, int stride);   // 0 = unsupported
+int launch_fused_band(const FusedArgs& a, int B, int k, int stride, hipStream_t st);
 
 // ---- convolution-side kernels (conv_kernels.hip) -----------------------------------------------
 // Stem: x [B][3][H][W] fp32 NCHW -> out [B][Ho][Wo][Cout] bf16, 3x3 stride 2 pad 1, + bias + act.

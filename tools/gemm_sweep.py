@@ -1,5 +1,7 @@
 """GEMM micro-benchmark (developer tool): per-shape time of k_gemm_bf16 through mi355_gemm_bf16."""
-import sys, time, torch
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+import os, sys, time, torch
 import imageretrievalresearch_amd as M
 from imageretrievalresearch_amd._lib import lib, check, stream_ptr
 dev = "cuda:0"
@@ -16,7 +18,7 @@ for (Mm, N, K) in shapes:
     bias = torch.zeros(Np, device=dev)
     out = torch.empty(Mm, N, device=dev, dtype=torch.bfloat16)
     def run():
-        check(lib().mi355_gemm_bf16(A.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr(), Mm, N, K, ldw, 1, stream_ptr(dev)))
+        check(lib().mi355_gemm_bf16(A.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr(), Mm, N, K, ldw, int(os.environ.get("ACT","1")), stream_ptr(dev)))
     for _ in range(3): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

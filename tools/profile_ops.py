@@ -1,4 +1,6 @@
 """Per-op timing table of one forward (developer tool): python tools_profile_ops.py [model] [batch]"""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 import sys
 import torch
 import imageretrievalresearch_amd as M
