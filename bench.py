@@ -53,8 +53,14 @@ def cpu_baseline(model_name, gallery_rows):
     images (BASELINE configs[0] batch) and the per-query CosineSimilarity+topk loop of train/train.py:250-251
     for 8 queries against the same-size gallery."""
     from oracle import effnet, rank as orank
-    torch.set_num_threads(os.cpu_count() or 1)
-    cores = torch.get_num_threads()
+    # the GPU box gives one GPU job a 16-core share (os.cpu_count() reports the whole 256-thread host and
+    # oversubscribing it made the oracle 20x slower); use what we are actually allowed to run on
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
+    torch.set_num_threads(cores)
     sd = effnet.init_state_dict(2, num_classes=0)
     x = torch.from_numpy(synth.uniform(1, (16, 3, 224, 224)))
     with torch.no_grad():
@@ -195,7 +201,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -533,8 +533,11 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t st) {
     // small-K layers are pure streaming (one or two K tiles): narrower tiles keep 4+ waves per SIMD resident
     static const int no_remap = getenv("MI355_NO_REMAP") ? atoi(getenv("MI355_NO_REMAP")) : 0;
     const_cast<GemmArgs&>(a).no_remap = no_remap;
-    static const int small_k_nt = getenv("MI355_SMALLK_NT") ? atoi(getenv("MI355_SMALLK_NT")) : 12;
-    const int nt = pick_nt(a.N, a.K <= 64 ? small_k_nt : 12);
+    // (measured, tools/gemm_sweep.py: N=192,K=32 runs 172 us as one 192-wide tile, 133 us as three 64-wide tiles;
+    //  N=144,K=24 is best as one 144-wide tile)
+    static const int small_k_nt = getenv("MI355_SMALLK_NT") ? atoi(getenv("MI355_SMALLK_NT")) : 0;
+    const int small_cap = small_k_nt ? small_k_nt : (a.N % 64 == 0 ? 4 : 9);
+    const int nt = pick_nt(a.N, a.K <= 64 ? small_cap : 12);
     if (a.M <= 64) return a.K >= 64 ? launch_nt<1, 64>(a, nt, st) : launch_nt<1, 32>(a, nt, st);
     return launch_nt<2, 32>(a, nt, st);
 }
