@@ -239,11 +239,10 @@ static int exec_op(ExecCtx& cx, const Op& op) {
             return launch_gemm_bf16(a, cx.st);
         }
         case OP_DW:
-            m->pool_nblk = dw_pool_blocks(conv_out(S[op.in].h, op.k, op.stride), conv_out(S[op.in].w, op.k, op.stride), op.cin);
             return launch_dwconv((const bf16_t*)cx.slot_ptr(op.in), (const bf16_t*)cx.w(op.w_off),
                                  (const float*)cx.w(op.b_off), (bf16_t*)cx.slot_ptr(op.out),
                                  op.pool ? (float*)cx.slot_ptr(SLOT_POOLPART) : nullptr, cx.nb, S[op.in].h, S[op.in].w,
-                                 op.cin, op.k, op.stride, op.act, cx.st);
+                                 op.cin, op.k, op.stride, op.act, &m->pool_nblk, cx.st);
         case OP_SE: {
             // the squeeze partials were produced by the preceding depthwise conv into SLOT_D's geometry
             const int ho = S[SLOT_D].h, wo = S[SLOT_D].w;

@@ -53,8 +53,9 @@ int launch_stem(const float* x, const float* w, const float* bias, bf16_t* out, 
 // pool_partial (optional): [B][dw_pool_blocks(...)][C] fp32 partial sums of the un-rounded output
 // (the SE squeeze), reduced in a fixed order.
 int dw_pool_blocks(int Ho, int Wo, int C);
+// pool_nblk (out): squeeze partials per image this launch produced (pool_partial is [B][nblk][C]).
 int launch_dwconv(const bf16_t* in, const bf16_t* w, const float* bias, bf16_t* out, float* pool_partial, int B,
-                  int H, int W, int C, int k, int stride, int act, hipStream_t st);
+                  int H, int W, int C, int k, int stride, int act, int* pool_nblk, hipStream_t st);
 
 // Squeeze-excite gate: s = (sum over nblk partials) / hw ; r = act1(W1 s + b1) ; gate = sigmoid(W2 r + b2).
 // W1 [rd][C] fp32, W2T [rd][C] fp32 (transposed).  gate out [B][C] fp32.
