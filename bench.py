@@ -170,8 +170,18 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         kernel_names = {"gemm": "k_gemm_bf16 (1x1 conv)", "dw": "k_dwconv (depthwise + SE squeeze)",
                         "fused": "k_fused_late (1x1 expand + depthwise + SE squeeze, expanded tensor in LDS)", "stem": "k_stem", "se": "k_se", "attn": "k_win_attn", "ln": "k_layernorm", "other": "other"}
+        # HBM bytes per launch of that family from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in
+        # separate runs, gfx950 x2 read correction) — cannot be collected from inside this process
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_effnet_b256.json")
+        if a.model == "efficientnet_b3a" and a.batch == 256 and os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f)["families"]
+            if fam in pmc:
+                traffic = pmc[fam]["hbm_bytes_per_launch"]
         roofline = {"bound": "hbm", "kernel": kernel_names[fam], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": "profiles/r01_pmc_traffic_effnet_b256.json (rocprofv3 --pmc, separate passes)" if traffic else None,
                     "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                     "family_ms_per_forward": {k: v["ms"] / 3 for k, v in prof.items() if v["launches"]}}
         embed_gbs = (tr["act_bytes"] + tr["weight_bytes"]) / t_embed / 1e9
