@@ -466,6 +466,157 @@ static int launch_big(const GemmArgs& a, hipStream_t st) {
     return OK;
 }
 
+// =====================================================================================
+// Streaming path for the early layers (W small enough to sit in LDS: N*K <= 32k elements, K <= 320):
+// the weights are loaded into LDS ONCE per workgroup and stay there; every wave then streams 16-row slabs of A
+// straight from HBM into MFMA fragments (a lane needs 16 contiguous bytes of one row: no LDS, no barrier in the
+// loop), multiplies against the resident W and writes its rows out.  Slabs are prefetched PF deep in registers
+// (8 VGPRs per slab per k-step), so each wave keeps several HBM requests in flight: these layers are pure
+// bandwidth (A or the output is 6x the other operand), the tiled kernel spent its time in per-tile
+// load -> barrier -> store chains.  Same prologue/epilogue contract as k_gemm_bf16 (gate, ReLU6, bias, act, residual).
+// =====================================================================================
+template <int NT, int KST>
+__global__ __launch_bounds__(256) void k_gemm_stream(const GemmArgs g) {
+    constexpr int PF = KST == 1 ? 4 : (KST <= 2 ? 3 : 1);     // slabs in flight per wave
+    constexpr int WLD = KST * 32 + 8;
+    constexpr int CLD = NT * 16 + 8;
+    extern __shared__ __attribute__((aligned(16))) bf16_t wsm[];   // [NT*16][WLD], then 4 x [16][CLD] output strips
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Npad = (g.N + 15) & ~15;
+    for (int id = tid; id < NT * 16 * KST * 4; id += 256) {
+        const int row = id / (KST * 4), c = id - row * (KST * 4);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < Npad && c * 8 < g.ldw) v = *reinterpret_cast<const u32x4*>(g.W + (size_t)row * g.ldw + c * 8);
+        *reinterpret_cast<u32x4*>(&wsm[row * WLD + c * 8]) = v;
+    }
+    __syncthreads();
+
+    bf16_t* cst = wsm + NT * 16 * WLD + wave * 16 * CLD;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nslabs = (g.M + 15) >> 4;
+    const int stride = gridDim.x * 4;
+    int slab = blockIdx.x * 4 + wave;
+
+    auto load_slab = [&](int sl, u32x4 (&dst)[KST]) {
+        const int m = sl * 16 + fr;
+#pragma unroll
+        for (int ks = 0; ks < KST; ++ks) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            const int k = ks * 32 + fq * 8;
+            if (sl < nslabs && m < g.M && k < g.K) {
+                v = *reinterpret_cast<const u32x4*>(g.A + (size_t)m * g.lda + k);
+                if (g.gate) v = gate_chunk(v, g.gate + (size_t)(m / g.rows_per_img) * g.gate_ld + k, g.a_relu6);
+                else if (g.a_relu6) v = relu6_chunk(v);
+            }
+            dst[ks] = v;
+        }
+    };
+
+    u32x4 ring[PF][KST];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) load_slab(slab + p * stride, ring[p]);
+
+    f32x4 bias[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+        const int n = ni * 16 + fq * 4;
+        bias[ni] = n < Npad ? *reinterpret_cast<const f32x4*>(g.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    while (slab < nslabs) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {          // static ring index: slot p holds slab + p*stride
+            const int sl = slab + p * stride;
+            if (sl < nslabs) {
+                f32x4 acc[NT];
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) acc[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KST; ++ks) {
+                    const bf16x8 af = *reinterpret_cast<bf16x8*>(&ring[p][ks]);
+#pragma unroll
+                    for (int ni = 0; ni < NT; ++ni) {
+                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(&wsm[(ni * 16 + fr) * WLD + ks * 32 + fq * 8]);
+                        acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[ni], 0, 0, 0);
+                    }
+                }
+                load_slab(sl + PF * stride, ring[p]);   // refill this slot PF slabs ahead
+                MI355_ACT_DISPATCH(g.act, {
+_Pragma("unroll")
+                    for (int ni = 0; ni < NT; ++ni) {
+                        acc[ni].x = act_c<ACT>(acc[ni].x + bias[ni].x); acc[ni].y = act_c<ACT>(acc[ni].y + bias[ni].y);
+                        acc[ni].z = act_c<ACT>(acc[ni].z + bias[ni].z); acc[ni].w = act_c<ACT>(acc[ni].w + bias[ni].w);
+                    }
+                })
+                // residual in registers (8-byte loads), then the slab goes through this wave's private LDS strip so
+                // the HBM writes are whole 16-byte-per-lane rows (32-byte fragments straight from the accumulator
+                // layout ran the pure-write layers at 2.2 TB/s)
+                const int m = sl * 16 + fr;
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) {
+                    const int n = ni * 16 + fq * 4;
+                    float v[4] = {acc[ni].x, acc[ni].y, acc[ni].z, acc[ni].w};
+                    if (g.res && m < g.M && n < g.N) {
+                        if (n + 3 < g.res_n) {
+                            const u32x2 rr = *reinterpret_cast<const u32x2*>(g.res + (size_t)m * g.ldr + n);
+                            v[0] += lo_bf(rr.x); v[1] += hi_bf(rr.x); v[2] += lo_bf(rr.y); v[3] += hi_bf(rr.y);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (n + r < g.res_n) v[r] += bf2f(g.res[(size_t)m * g.ldr + n + r]);
+                        }
+                    }
+                    u32x2 o;
+                    o.x = pack2bf(v[0], v[1]);
+                    o.y = pack2bf(v[2], v[3]);
+                    *reinterpret_cast<u32x2*>(&cst[fr * CLD + n]) = o;
+                }
+                // (same wave wrote and reads: LDS ops complete in order, no barrier needed)
+                constexpr int CPR = NT * 2;               // 16-byte chunks per row (padded width)
+#pragma unroll
+                for (int i = 0; i < (16 * CPR + 63) / 64; ++i) {
+                    const int id = lane + 64 * i;
+                    const int row = id / CPR, c = id - row * CPR;
+                    const int mm = sl * 16 + row;
+                    if (id < 16 * CPR && mm < g.M && c * 8 < g.N)
+                        *reinterpret_cast<u32x4*>((bf16_t*)g.out + (size_t)mm * g.ldo + c * 8) =
+                            *reinterpret_cast<const u32x4*>(&cst[row * CLD + c * 8]);
+                }
+            }
+        }
+        slab += PF * stride;
+    }
+}
+
+template <int NT, int KST>
+static int launch_stream_cfg(const GemmArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)NT * 16 * (KST * 32 + 8) * 2 + (size_t)4 * 16 * (NT * 16 + 8) * 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_stream<NT, KST>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        attr_done = true;
+    }
+    const int nslabs = cdiv(a.M, 16);
+    int blocks = cdiv(nslabs, 4);
+    if (blocks > 256 * 8) blocks = 256 * 8;   // a few workgroups per CU, each streaming many slabs
+    hipLaunchKernelGGL((k_gemm_stream<NT, KST>), dim3(blocks), dim3(256), lds, st, a);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
+// returns -1 when the shape is not covered (caller falls back to the tiled kernel).
+// Measured per layer (profiles/r01_effnet_per_op.txt vs tools/gemm_sweep.py): streaming wins where the output row is
+// wide and K is one k-step (24->144 @112x112: 0.375 -> 0.284 ms); the tiled kernel wins on 32->192 (0.131 vs 0.145),
+// 48->288 (0.056 vs 0.097) and on the gated projections, so only the first shape class is routed here.
+static int try_launch_stream(const GemmArgs& a, hipStream_t st) {
+    if (a.out_f32 || a.M < 4096 || a.N % 8 || a.ldo % 8 || a.gate || a.a_relu6) return -1;
+    const int kst = (a.K + 31) / 32;
+    const int nt = (a.N + 15) / 16;
+    if (kst == 1 && nt == 9) return launch_stream_cfg<9, 1>(a, st);
+    return -1;
+}
+
 // Tile selection.  BN = 16*NT minimising padded columns (prefer fewer, larger tiles: fewer A-panel re-reads);
 // BM = 64 when a 128-row tiling would leave the 256 CUs with < 4 blocks each (late 14x14 / 7x7 layers are
 // latency-bound: more, smaller blocks overlap their load latency); BK = 64 once K >= 64.
@@ -533,12 +684,20 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t st) {
     // small-K layers are pure streaming (one or two K tiles): narrower tiles keep 4+ waves per SIMD resident
     static const int no_remap = getenv("MI355_NO_REMAP") ? atoi(getenv("MI355_NO_REMAP")) : 0;
     const_cast<GemmArgs&>(a).no_remap = no_remap;
+    static const int use_stream = getenv("MI355_GEMM_STREAM") ? atoi(getenv("MI355_GEMM_STREAM")) : 1;
+    if (use_stream) {
+        const int e = try_launch_stream(a, st);
+        if (e >= 0) return e;
+    }
     // (measured, tools/gemm_sweep.py: N=192,K=32 runs 172 us as one 192-wide tile, 133 us as three 64-wide tiles;
     //  N=144,K=24 is best as one 144-wide tile)
     static const int small_k_nt = getenv("MI355_SMALLK_NT") ? atoi(getenv("MI355_SMALLK_NT")) : 0;
     const int small_cap = small_k_nt ? small_k_nt : (a.N % 64 == 0 ? 4 : 9);
     const int nt = pick_nt(a.N, a.K <= 64 ? small_cap : 12);
     if (a.M <= 64) return a.K >= 64 ? launch_nt<1, 64>(a, nt, st) : launch_nt<1, 32>(a, nt, st);
+    // few 128-row tiles (late 7x7 / 14x14 layers): 64-row tiles double the workgroups so their K loops overlap
+    static const int small_m = getenv("MI355_GEMM_SMALLM") ? atoi(getenv("MI355_GEMM_SMALLM")) : 0;
+    if (small_m && (long)cdiv(a.M, 128) * cdiv(a.N, nt * 16) < small_m) return launch_nt<1, 32>(a, nt, st);
     return launch_nt<2, 32>(a, nt, st);
 }
 
