@@ -9,16 +9,19 @@ for device memory, streams and torch.distributed only.
 from . import synth  # noqa: F401
 from ._lib import MI355Error, lib, LIB_PATH  # noqa: F401
 from . import models  # noqa: F401
-from .rank import (ContrastiveLoss, CosineSimilarity, Gallery, cosine_scores, cosine_topk,  # noqa: F401
+from .rank import (ContrastiveLoss, CosineEmbeddingLoss, CosineSimilarity, Gallery, cosine_scores, cosine_topk,  # noqa: F401
                    distinct_class_topn, hit_counts, l2_normalize_rows, merge_topk, pair_cosine,
-                   retrieval_metrics, synth_fill, topk)
+                   retrieval_metrics, synth_fill, topk, validation_metrics)
 
-__all__ = ["create_model", "list_models", "ContrastiveLoss", "CosineSimilarity", "Gallery", "cosine_scores",
+__all__ = ["create_model", "list_models", "load_checkpoint", "strip_lightning_prefix", "ContrastiveLoss", "CosineEmbeddingLoss", "validation_metrics", "CosineSimilarity", "Gallery", "cosine_scores",
            "cosine_topk", "pair_cosine", "topk", "merge_topk", "hit_counts", "distinct_class_topn",
            "retrieval_metrics", "l2_normalize_rows", "synth_fill", "ShardedGallery", "MI355Error"]
 
 
 def __getattr__(name):  # lazy: models/sharded import torch.nn / torch.distributed
+    if name in ("load_checkpoint", "strip_lightning_prefix"):
+        from . import checkpoint
+        return getattr(checkpoint, name)
     if name in ("create_model", "list_models", "ConvInput", "with_conv_input"):
         from . import models
         return getattr(models, name)

@@ -32,6 +32,7 @@ PROTOTYPES = {
     "mi355_merge_topk": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
     "mi355_pair_cosine": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_float, vp, vp]),
     "mi355_contrastive_loss": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_int, vp, vp, vp]),
+    "mi355_cosine_embedding_loss": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_int, vp, vp]),
     "mi355_hit_counts": (C.c_int, [vp, C.c_int64, C.c_int, vp, vp, vp, vp]),
     "mi355_distinct_class_topn": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp, C.c_int, vp, vp, vp, vp]),
     "mi355_model_create": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(vp)]),

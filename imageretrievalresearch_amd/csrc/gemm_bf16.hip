@@ -71,7 +71,6 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(const GemmArgs g, const int n
         const int bid = blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        if (g.no_remap & 1) logical = bid;
     }
     const int mb = logical / n_tiles, nb = logical - mb * n_tiles;
     const int m0 = mb * BM;
@@ -134,8 +133,9 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(const GemmArgs g, const int n
 #pragma unroll
         for (int j = 0; j < WM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nt = (g.no_remap & 4) ? 0 : (g.K + BK - 1) / BK;
-    if (nt) { load_tile(0); store_tile(0); }
+    const int nt = (g.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
     __syncthreads();
 
     const int fr = lane & 15;          // fragment row (n for W, m for A)
@@ -172,7 +172,6 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(const GemmArgs g, const int n
         __syncthreads();
     }
 
-    if (g.no_remap & 2) { if (acc[0][0].x == 12345.f) ((float*)g.out)[0] = 1.f; return; }
     // bias + activation once, straight-line per activation (see MI355_ACT_DISPATCH); the store paths below only
     // pack / add the residual / write.
     MI355_ACT_DISPATCH(g.act, {
@@ -682,8 +681,6 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t st) {
         ((uintptr_t)a.A % 16 == 0) && a.lda % 8 == 0)
         return launch_big(a, st);
     // small-K layers are pure streaming (one or two K tiles): narrower tiles keep 4+ waves per SIMD resident
-    static const int no_remap = getenv("MI355_NO_REMAP") ? atoi(getenv("MI355_NO_REMAP")) : 0;
-    const_cast<GemmArgs&>(a).no_remap = no_remap;
     static const int use_stream = getenv("MI355_GEMM_STREAM") ? atoi(getenv("MI355_GEMM_STREAM")) : 1;
     if (use_stream) {
         const int e = try_launch_stream(a, st);
@@ -691,13 +688,10 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t st) {
     }
     // (measured, tools/gemm_sweep.py: N=192,K=32 runs 172 us as one 192-wide tile, 133 us as three 64-wide tiles;
     //  N=144,K=24 is best as one 144-wide tile)
-    static const int small_k_nt = getenv("MI355_SMALLK_NT") ? atoi(getenv("MI355_SMALLK_NT")) : 0;
-    const int small_cap = small_k_nt ? small_k_nt : (a.N % 64 == 0 ? 4 : 9);
+    const int small_cap = a.N % 64 == 0 ? 4 : 9;
     const int nt = pick_nt(a.N, a.K <= 64 ? small_cap : 12);
     if (a.M <= 64) return a.K >= 64 ? launch_nt<1, 64>(a, nt, st) : launch_nt<1, 32>(a, nt, st);
-    // few 128-row tiles (late 7x7 / 14x14 layers): 64-row tiles double the workgroups so their K loops overlap
-    static const int small_m = getenv("MI355_GEMM_SMALLM") ? atoi(getenv("MI355_GEMM_SMALLM")) : 0;
-    if (small_m && (long)cdiv(a.M, 128) * cdiv(a.N, nt * 16) < small_m) return launch_nt<1, 32>(a, nt, st);
+    // (64-row tiles for the late layers with few 128-row tiles were measured: no change, so they are not used)
     return launch_nt<2, 32>(a, nt, st);
 }
 

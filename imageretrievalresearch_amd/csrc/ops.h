@@ -20,7 +20,6 @@ struct GemmArgs {
     int M, N, K;
     int act;
     int a_relu6;
-    int no_remap;   // diagnosis: 1 = plain blockIdx tile order (no XCD-aware remap)
 };
 int launch_gemm_bf16(const GemmArgs& a, hipStream_t st);
 

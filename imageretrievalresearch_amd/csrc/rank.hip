@@ -366,6 +366,35 @@ __global__ __launch_bounds__(1024) void k_contrastive(const float* __restrict__ 
     }
 }
 
+// torch.nn.CosineEmbeddingLoss (ATen cosine_embedding_loss): cos = xy / sqrt((xx + 1e-12)(yy + 1e-12));
+// target +1 -> 1 - cos, target -1 -> max(0, cos - margin); mean (or sum) over rows in a fixed order.
+__global__ __launch_bounds__(1024) void k_cos_embedding_loss(const float* __restrict__ f1, const float* __restrict__ f2,
+                                                             i64 rows, int dim, float target, float margin, int mean,
+                                                             float* __restrict__ out) {
+    __shared__ float part[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc = 0.f;
+    for (i64 r = wave; r < rows; r += 16) {
+        const float* x = f1 + r * dim;
+        const float* y = f2 + r * dim;
+        float xx = 0.f, yy = 0.f, xy = 0.f;
+        for (int i = lane; i < dim; i += 64) {
+            const float u = x[i], v = y[i];
+            xx += u * u; yy += v * v; xy += u * v;
+        }
+        xx = wave_sum(xx); yy = wave_sum(yy); xy = wave_sum(xy);
+        const float c = xy / sqrtf((xx + 1e-12f) * (yy + 1e-12f));
+        acc += target > 0.f ? 1.0f - c : fmaxf(c - margin, 0.f);
+    }
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        out[0] = mean ? t / (float)rows : t;
+    }
+}
+
 __global__ void k_hit_counts(const i64* __restrict__ idx, i64 Q, int k, const i64* __restrict__ qcls,
                              const i64* __restrict__ gcls, i64* __restrict__ counts) {
     const i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -662,6 +691,17 @@ int mi355_contrastive_loss(const float* fm1, const float* fm2, int64_t rows, int
     MI355_REQUIRE(rows >= 1 && dim >= 1, "contrastive_loss: bad shape rows=%lld dim=%d", (long long)rows, dim);
     hipLaunchKernelGGL(k_contrastive, dim3(1), dim3(1024), 0, (hipStream_t)stream, fm1, fm2, (i64)rows, dim, label,
                        margin, mean, out, per_row);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
+int mi355_cosine_embedding_loss(const float* x1, const float* x2, int64_t rows, int dim, float target, float margin,
+                                int mean, float* out, void* stream) {
+    MI355_REQUIRE(x1 && x2 && out, "cosine_embedding_loss: null pointer");
+    MI355_REQUIRE(rows >= 1 && dim >= 1, "cosine_embedding_loss: bad shape rows=%lld dim=%d", (long long)rows, dim);
+    MI355_REQUIRE(target == 1.0f || target == -1.0f, "cosine_embedding_loss: target must be +1 or -1");
+    hipLaunchKernelGGL(k_cos_embedding_loss, dim3(1), dim3(1024), 0, (hipStream_t)stream, x1, x2, (i64)rows, dim, target,
+                       margin, mean, out);
     MI355_LAUNCH_CHECK();
     return OK;
 }

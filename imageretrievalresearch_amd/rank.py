@@ -212,6 +212,47 @@ class ContrastiveLoss(torch.nn.Module):
         return out
 
 
+class CosineEmbeddingLoss(torch.nn.Module):
+    """``torch.nn.CosineEmbeddingLoss(margin)`` for the reference's call shape: two (B,D) batches and a scalar
+    target of +1 or -1 (``labels["pos"]`` / ``labels["neg"]``, train/train.py:81, :214-216).  Forward only."""
+
+    def __init__(self, margin: float = 0.0, reduction: str = "mean"):
+        super().__init__()
+        if reduction not in ("mean", "sum"):
+            raise MI355Error("reduction must be 'mean' or 'sum'")
+        self.margin, self.reduction = margin, reduction
+
+    def forward(self, input1, input2, target):
+        a, b = _f32c(input1, "input1"), _f32c(input2, "input2")
+        if a.shape != b.shape or a.dim() != 2:
+            raise MI355Error(f"CosineEmbeddingLoss expects two (B,D) tensors, got {tuple(a.shape)} / {tuple(b.shape)}")
+        t = float(target.reshape(-1)[0].item()) if torch.is_tensor(target) else float(target)
+        if torch.is_tensor(target) and target.numel() != 1:
+            raise MI355Error("only a scalar (broadcast) target is supported, as in the reference")
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device):
+            check(lib().mi355_cosine_embedding_loss(a.data_ptr(), b.data_ptr(), a.shape[0], a.shape[1], t,
+                                                    float(self.margin), int(self.reduction == "mean"), out.data_ptr(),
+                                                    stream_ptr(a.device)))
+        return out
+
+
+def validation_metrics(fm_ims, fm_poss, fm_negs, clss, margin: float = 0.5, k: int = 3):
+    """The metric half of ``validation_step`` (train/train.py:308-373) as a handful of batched launches instead of a
+    Python loop with one cosine + topk + ``.item()`` per row: cosine-embedding losses (+1 / -1 targets), mean pair
+    cosines (``cos_sims`` / ``cos_unsims``), and top-1 / top-3 of every query against the positives of the batch.
+    Values stay on the device; nothing here synchronises."""
+    cel = CosineEmbeddingLoss(margin)
+    loss_pos = cel(fm_ims, fm_poss, 1.0)
+    loss_neg = cel(fm_ims, fm_negs, -1.0)
+    vals, inds = cosine_topk(fm_ims, fm_poss, min(k, fm_poss.shape[0]))
+    counts = hit_counts(inds, clss, clss)
+    n = fm_ims.shape[0]
+    return {"loss_cos_poss": loss_pos, "loss_cos_negs": loss_neg, "loss_cos": loss_pos + loss_neg,
+            "cos_sims": pair_cosine(fm_ims, fm_poss).mean(), "cos_unsims": pair_cosine(fm_ims, fm_negs).mean(),
+            "top1": counts[0].float() / n, "top3": counts[1].float() / n, "topk_vals": vals, "topk_inds": inds}
+
+
 def hit_counts(idx: torch.Tensor, query_cls: torch.Tensor, gallery_cls: torch.Tensor):
     """train/train.py:252-255 -> (top1_hits, top3_hits) as a device int64[2] tensor (no sync)."""
     require_cuda(idx, "idx")

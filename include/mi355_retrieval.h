@@ -90,6 +90,11 @@ int mi355_pair_cosine(const float* a, const float* b, int64_t rows, int dim, flo
 int mi355_contrastive_loss(const float* fm1, const float* fm2, int64_t rows, int dim, float label,
                            float margin, int mean, float* out, float* per_row, void* stream);
 
+/* torch.nn.CosineEmbeddingLoss(margin)(x1, x2, target) with a scalar target of +1 or -1 broadcast over the rows —
+ * the validation-step loss of train/train.py:214-216, :308-310.  out[0] = mean (or sum). */
+int mi355_cosine_embedding_loss(const float* x1, const float* x2, int64_t rows, int dim, float target, float margin,
+                                int mean, float* out, void* stream);
+
 /* Hit counting, train/train.py:252-255: counts[0] += #queries whose class equals the class of
  * their top-1 result, counts[1] += #queries whose class is among their top-min(3,k).
  * idx [Q][k] int64 into gallery_cls; counts int64[2] must be zeroed by the caller. */

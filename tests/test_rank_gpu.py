@@ -182,3 +182,28 @@ def test_gallery_object_and_metrics():
     np.testing.assert_allclose(v[:, 0].cpu().numpy(), 1.0, atol=SCORE_TOL)
     m = M.retrieval_metrics(dev(emb[:64]), dev(emb[:64]), dev(cls[:64]))
     assert m["top1"] == 1.0 and m["top3"] == 1.0 and abs(m["scores"] - 1.0) < SCORE_TOL
+
+
+def test_cosine_embedding_loss_and_validation_metrics():
+    """f-4: train/train.py:308-373 — against torch's own CosineEmbeddingLoss / per-row loop on the CPU."""
+    q, p, n = synth.normal(61, (48, 1536)), synth.normal(62, (48, 1536)), synth.normal(63, (48, 1536))
+    p = (0.7 * q + 0.3 * p).astype(np.float32)                          # positives correlate with their query
+    cls = (np.arange(48) % 12).astype(np.int64)
+    tq, tp, tn = (torch.from_numpy(x) for x in (q, p, n))
+    for margin in (0.0, 0.5):
+        ref = torch.nn.CosineEmbeddingLoss(margin=margin)
+        for tgt, other in ((1.0, tp), (-1.0, tn)):
+            want = ref(tq, other, torch.tensor(tgt).unsqueeze(0)).item()      # labels["pos"/"neg"], train/train.py:81
+            got = M.CosineEmbeddingLoss(margin)(dev(q), other.to(DEV), torch.tensor(tgt).unsqueeze(0)).item()
+            assert got == pytest.approx(want, rel=1e-5, abs=1e-7), (margin, tgt)
+    m = M.validation_metrics(dev(q), dev(p), dev(n), dev(cls), margin=0.5)
+    cos = torch.nn.CosineSimilarity(dim=1, eps=1e-6)
+    top1 = top3 = 0
+    for idx in range(48):                                                # train/train.py:342-362, literally
+        sim = cos(tq[idx].unsqueeze(0), tp)
+        vals, inds = torch.topk(sim, k=3)
+        top3 += int(cls[idx] in cls[inds.numpy()])
+        top1 += int(cls[idx] == cls[inds[0].item()])
+    assert m["top1"].item() == pytest.approx(top1 / 48) and m["top3"].item() == pytest.approx(top3 / 48)
+    assert m["cos_sims"].item() == pytest.approx(cos(tq, tp).mean().item(), abs=1e-5)
+    assert m["cos_unsims"].item() == pytest.approx(cos(tq, tn).mean().item(), abs=1e-5)
