@@ -547,6 +547,36 @@ __global__ __launch_bounds__(256) void k_conv_input_silu(const float* __restrict
     for (int co = 0; co < 3; ++co) ob[((size_t)co * H + oy) * W + ox] = silu_f(acc[co]);
 }
 
+// SquarePad(fill) -> ToTensor (/255) -> Normalize((x - mean) / std): uint8 HWC in, fp32 CHW out (S = max(h, w)).
+// utils/square_pad.py:20-36 + inference/inference.py:48-52.  One rounding per fp32 op, like torch on the CPU.
+__global__ __launch_bounds__(256) void k_square_pad_normalize(const unsigned char* __restrict__ img, int h, int w, int S,
+                                                             int hp, int vp, int fill, float m0, float m1, float m2,
+                                                             float s0, float s1, float s2, float* __restrict__ out) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= S || y >= S) return;
+    const int iy = y - vp, ix = x - hp;
+    int p0 = fill, p1 = fill, p2 = fill;
+    if (iy >= 0 && iy < h && ix >= 0 && ix < w) {
+        const unsigned char* p = img + ((size_t)iy * w + ix) * 3;
+        p0 = p[0]; p1 = p[1]; p2 = p[2];
+    }
+    const size_t plane = (size_t)S * S, o = (size_t)y * S + x;
+    out[o] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)p0, 255.0f), m0), s0);
+    out[plane + o] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)p1, 255.0f), m1), s1);
+    out[2 * plane + o] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)p2, 255.0f), m2), s2);
+}
+
+int launch_square_pad_normalize(const unsigned char* img, int h, int w, int fill, const float* mean, const float* stdv,
+                                float* out, hipStream_t st) {
+    const int S = h > w ? h : w;
+    const int hp = (S - w) / 2, vp = (S - h) / 2;
+    hipLaunchKernelGGL(k_square_pad_normalize, dim3(cdiv(S, 64), cdiv(S, 4)), dim3(256), 0, st, img, h, w, S, hp, vp, fill,
+                       mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2], out);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
 int launch_conv_input_silu(const float* x, const float* w, int B, int H, int W, float* out, hipStream_t st) {
     dim3 grid(cdiv(W, 32), cdiv(H, 8), B);
     hipLaunchKernelGGL(k_conv_input_silu, grid, dim3(256), 0, st, x, w, out, H, W);

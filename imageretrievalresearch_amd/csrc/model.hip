@@ -687,6 +687,15 @@ int mi355_gemm_bf16(const void* A, const void* W, const float* bias, void* out, 
     return launch_gemm_bf16(a, (hipStream_t)stream);
 }
 
+int mi355_square_pad_normalize(const unsigned char* img, int h, int w, int fill, const float* mean, const float* stdv,
+                               float* out, void* stream) {
+    MI355_REQUIRE(img && mean && stdv && out, "square_pad_normalize: null pointer");
+    MI355_REQUIRE(h >= 1 && w >= 1 && h <= 16384 && w <= 16384, "square_pad_normalize: bad image size %dx%d", h, w);
+    MI355_REQUIRE(fill >= 0 && fill <= 255, "square_pad_normalize: fill must be a byte value");
+    for (int c = 0; c < 3; ++c) MI355_REQUIRE(stdv[c] != 0.f, "square_pad_normalize: std[%d] is zero", c);
+    return launch_square_pad_normalize(img, h, w, fill, mean, stdv, out, (hipStream_t)stream);
+}
+
 int mi355_conv_input_silu(const float* x, const float* w, int B, int H, int W, float* out, void* stream) {
     MI355_REQUIRE(x && w && out, "conv_input_silu: null pointer");
     MI355_REQUIRE(B >= 1 && H >= 1 && W >= 1, "conv_input_silu: bad shape");

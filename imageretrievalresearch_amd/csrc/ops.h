@@ -67,6 +67,10 @@ int launch_gap(const bf16_t* in, float* pooled, bf16_t* pooled_bf16, int B, int 
 // NHWC bf16 [B][HW][C] -> NCHW fp32 [B][Cvalid][HW] (forward_features output, taps).
 int launch_nhwc_to_nchw_f32(const bf16_t* in, float* out, int B, int HW, int C, int Cvalid, hipStream_t st);
 
+// SquarePad + ToTensor + Normalize: uint8 HWC (h, w, 3) -> fp32 CHW (3, S, S), S = max(h, w); mean/std are HOST arrays.
+int launch_square_pad_normalize(const unsigned char* img, int h, int w, int fill, const float* mean, const float* stdv,
+                                float* out, hipStream_t st);
+
 // conv_input pre-stem: SiLU(conv3x3 s1 p1, 3->3, no bias), fp32 NCHW in/out.
 int launch_conv_input_silu(const float* x, const float* w, int B, int H, int W, float* out, hipStream_t st);
 

@@ -184,6 +184,12 @@ int mi355_model_profile_ops(mi355_model_t m, int B, int H, int W, int max_ops, d
 int mi355_gemm_bf16(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int ldw, int act,
                     void* stream);
 
+/* Inference pre-processing: SquarePad(fill) -> ToTensor -> Normalize, utils/square_pad.py:20-36 +
+ * inference/inference.py:48-52.  img: uint8 RGB, HWC (h, w, 3) on the device; mean/std: HOST float[3];
+ * out: fp32 (3, S, S) with S = max(h, w), i.e. one image slot of the model's NCHW input batch. */
+int mi355_square_pad_normalize(const unsigned char* img, int h, int w, int fill, const float* mean, const float* stdv,
+                               float* out, void* stream);
+
 /* conv_input pre-stem (inference/inference.py:103-105): out = SiLU(Conv2d(3,3,3,1,1,bias=False)(x)),
  * x/out [B][3][H][W] fp32 NCHW, w [3][3][3][3] fp32 (device). */
 int mi355_conv_input_silu(const float* x, const float* w, int B, int H, int W, float* out, void* stream);
