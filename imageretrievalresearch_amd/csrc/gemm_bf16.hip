@@ -36,6 +36,18 @@ __device__ __forceinline__ u32x4 gate_chunk(u32x4 v, const float* __restrict__ g
     return o;
 }
 
+__device__ __forceinline__ u32x4 gate_chunk_regs(u32x4 v, f32x4 g0, f32x4 g1, int relu6) {
+    float f[8] = {lo_bf(v.x) * g0.x, hi_bf(v.x) * g0.y, lo_bf(v.y) * g0.z, hi_bf(v.y) * g0.w,
+                  lo_bf(v.z) * g1.x, hi_bf(v.z) * g1.y, lo_bf(v.w) * g1.z, hi_bf(v.w) * g1.w};
+    if (relu6) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = fminf(fmaxf(f[i], 0.f), 6.f);
+    }
+    u32x4 o;
+    o.x = pack2bf(f[0], f[1]); o.y = pack2bf(f[2], f[3]); o.z = pack2bf(f[4], f[5]); o.w = pack2bf(f[6], f[7]);
+    return o;
+}
+
 __device__ __forceinline__ u32x4 relu6_chunk(u32x4 v) {
     float f[8] = {lo_bf(v.x), hi_bf(v.x), lo_bf(v.y), hi_bf(v.y), lo_bf(v.z), hi_bf(v.z), lo_bf(v.w), hi_bf(v.w)};
 #pragma unroll
@@ -270,7 +282,15 @@ __device__ __forceinline__ void glds16(const bf16_t* gsrc, bf16_t* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// GATED = the SE-gated (and/or ReLU6'd) projection layers: the DMA cannot transform A on the way to LDS, so the gate is
+// applied to the A FRAGMENTS after the LDS read (same value and rounding as gating on load: bf16(A * g)); the four
+// waves then split M only (32 rows x all 128 columns each) so that no A fragment is gated twice.
+// K does not have to be a multiple of 64: lanes whose 16-byte chunk lies past K (or past row M / N) read from a
+// zero page instead (g.zeros), so no garbage ever enters the accumulation.
+template <bool GATED, bool KTAIL>
 __global__ __launch_bounds__(256) void k_gemm_big(const GemmArgs g, const int n_tiles, const int nwg) {
+    constexpr int MI = GATED ? 2 : 4;      // 16-row sub-tiles per wave
+    constexpr int NI = GATED ? 8 : 4;      // 16-column sub-tiles per wave
     extern __shared__ __attribute__((aligned(16))) bf16_t bsm[];
     bf16_t* As = bsm;                              // [2][128*64]
     bf16_t* Ws = bsm + 2 * BG_BM * BG_BK;          // [2][128*64]
@@ -288,54 +308,103 @@ __global__ __launch_bounds__(256) void k_gemm_big(const GemmArgs g, const int n_
     // staging: wave w issues 4 A pieces and 4 W pieces per tile; piece p covers tile rows p*8 .. p*8+7
     const bf16_t* a_src[4];
     const bf16_t* w_src[4];
+    int k_off[4];
+    bool a_ok[4], w_ok[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = (wave * 4 + i) * 8 + (lane >> 3);
         const int lchunk = (lane & 7) ^ ((row >> 1) & 7);
-        const int m = min(m0 + row, g.M - 1);
-        const int n = min(n0 + row, Npad - 1);
-        a_src[i] = g.A + (size_t)m * g.lda + lchunk * 8;
-        w_src[i] = g.W + (size_t)n * g.ldw + lchunk * 8;
+        k_off[i] = lchunk * 8;
+        a_ok[i] = (m0 + row) < g.M;
+        w_ok[i] = (n0 + row) < Npad;
+        a_src[i] = g.A + (size_t)(a_ok[i] ? m0 + row : 0) * g.lda + lchunk * 8;
+        w_src[i] = g.W + (size_t)(w_ok[i] ? n0 + row : 0) * g.ldw + lchunk * 8;
     }
     auto stage = [&](int buf, int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int piece = wave * 4 + i;            // wave-uniform
-            glds16(a_src[i] + k0, As + buf * BG_BM * BG_BK + piece * 512);
-            glds16(w_src[i] + k0, Ws + buf * BG_BN * BG_BK + piece * 512);
+            // KTAIL = false: K and ldw are multiples of 64 and out-of-range rows were clamped to row 0 (finite data,
+            // never stored), so the loop has no selects; KTAIL = true routes every out-of-range chunk to the zero page
+            const bf16_t* pa = KTAIL ? ((a_ok[i] && k0 + k_off[i] < g.K) ? a_src[i] + k0 : g.zeros) : a_src[i] + k0;
+            const bf16_t* pw = KTAIL ? ((w_ok[i] && k0 + k_off[i] < g.ldw) ? w_src[i] + k0 : g.zeros) : w_src[i] + k0;
+            glds16(pa, As + buf * BG_BM * BG_BK + piece * 512);
+            glds16(pw, Ws + buf * BG_BN * BG_BK + piece * 512);
         }
     };
 
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = GATED ? wave : (wave >> 1), wn = GATED ? 0 : (wave & 1);
     const int fr = lane & 15, fq = lane >> 4;
-    f32x4 acc[4][4];   // [ni][mi]
+    const int row_base = wm * (MI * 16), col_base = wn * (NI * 16);
+    f32x4 acc[NI][MI];   // [ni][mi]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nt = g.K / BG_BK;
+    const float* gate_row[MI];
+    if (GATED) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = min(m0 + row_base + mi * 16 + fr, g.M - 1);
+            gate_row[mi] = g.gate ? g.gate + (size_t)(m / g.rows_per_img) * g.gate_ld + fq * 8 : nullptr;
+        }
+    }
+
+    // gate values for one K-tile (this lane's 8 k-values per k-step), fetched one tile ahead so the L2 latency
+    // hides behind the previous tile's MFMAs
+    f32x4 gnext[MI][2][2];
+    auto load_gate = [&](int t) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int k = t * BG_BK + ks * 32;
+                const bool ok = GATED && g.gate && (k + fq * 8 < g.K);
+                gnext[mi][ks][0] = ok ? *reinterpret_cast<const f32x4*>(gate_row[mi] + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                gnext[mi][ks][1] = ok ? *reinterpret_cast<const f32x4*>(gate_row[mi] + k + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+    };
+
+    const int nt = (g.K + BG_BK - 1) / BG_BK;
     stage(0, 0);
+    if (GATED && g.gate) load_gate(0);
     __syncthreads();   // the fence drains vmcnt for the LDS-DMA as well
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         if (t + 1 < nt) stage(buf ^ 1, (t + 1) * BG_BK);
+        f32x4 gcur[MI][2][2];
+        if (GATED && g.gate) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) { gcur[mi][ks][0] = gnext[mi][ks][0]; gcur[mi][ks][1] = gnext[mi][ks][1]; }
+            if (t + 1 < nt) load_gate(t + 1);
+        }
         const bf16_t* as = As + buf * BG_BM * BG_BK;
         const bf16_t* ws = Ws + buf * BG_BN * BG_BK;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[4], wf[4];
+            bf16x8 af[MI], wf[NI];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ra = wm * 64 + i * 16 + fr;
-                const int rw = wn * 64 + i * 16 + fr;
-                af[i] = *reinterpret_cast<const bf16x8*>(&as[ra * 64 + (((ks * 4 + fq) ^ ((ra >> 1) & 7)) << 3)]);
+            for (int i = 0; i < MI; ++i) {
+                const int ra = row_base + i * 16 + fr;
+                u32x4 v = *reinterpret_cast<const u32x4*>(&as[ra * 64 + (((ks * 4 + fq) ^ ((ra >> 1) & 7)) << 3)]);
+                if (GATED) {
+                    if (g.gate) v = gate_chunk_regs(v, gcur[i][ks][0], gcur[i][ks][1], g.a_relu6);   // zeros past K
+                    else if (g.a_relu6) v = relu6_chunk(v);
+                }
+                af[i] = *reinterpret_cast<bf16x8*>(&v);
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int rw = col_base + i * 16 + fr;
                 wf[i] = *reinterpret_cast<const bf16x8*>(&ws[rw * 64 + (((ks * 4 + fq) ^ ((rw >> 1) & 7)) << 3)]);
             }
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
         }
         __syncthreads();   // next tile has landed (vmcnt(0)) and everyone is done reading this one
@@ -344,12 +413,12 @@ __global__ __launch_bounds__(256) void k_gemm_big(const GemmArgs g, const int n_
     // epilogue (same contract as k_gemm_bf16): lane holds n = .. + fq*4 + r, m = .. + fr
     MI355_ACT_DISPATCH(g.act, {
 _Pragma("unroll")
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + wn * 64 + ni * 16 + fq * 4;
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + col_base + ni * 16 + fq * 4;
             f32x4 b = {0.f, 0.f, 0.f, 0.f};
             if (n < Npad) b = *reinterpret_cast<const f32x4*>(g.bias + n);
 _Pragma("unroll")
-            for (int mi = 0; mi < 4; ++mi) {
+            for (int mi = 0; mi < MI; ++mi) {
                 acc[ni][mi].x = act_c<ACT>(acc[ni][mi].x + b.x); acc[ni][mi].y = act_c<ACT>(acc[ni][mi].y + b.y);
                 acc[ni][mi].z = act_c<ACT>(acc[ni][mi].z + b.z); acc[ni][mi].w = act_c<ACT>(acc[ni][mi].w + b.w);
             }
@@ -360,11 +429,11 @@ _Pragma("unroll")
         constexpr int CLD = BG_BN + 8;
         bf16_t* Cs = bsm;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int ml = wm * 64 + mi * 16 + fr;
+        for (int mi = 0; mi < MI; ++mi) {
+            const int ml = row_base + mi * 16 + fr;
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int nl = wn * 64 + ni * 16 + fq * 4;
+            for (int ni = 0; ni < NI; ++ni) {
+                const int nl = col_base + ni * 16 + fq * 4;
                 u32x2 o;
                 o.x = pack2bf(acc[ni][mi].x, acc[ni][mi].y);
                 o.y = pack2bf(acc[ni][mi].z, acc[ni][mi].w);
@@ -388,11 +457,11 @@ _Pragma("unroll")
         constexpr int FLD = BG_BN + 4;
         float* Cf = reinterpret_cast<float*>(bsm);   // [128][132] fp32 = 67.6 KB
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int ml = wm * 64 + mi * 16 + fr;
+        for (int mi = 0; mi < MI; ++mi) {
+            const int ml = row_base + mi * 16 + fr;
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int nl = wn * 64 + ni * 16 + fq * 4;
+            for (int ni = 0; ni < NI; ++ni) {
+                const int nl = col_base + ni * 16 + fq * 4;
                 *reinterpret_cast<f32x4*>(&Cf[ml * FLD + nl]) = acc[ni][mi];
             }
         }
@@ -416,12 +485,12 @@ _Pragma("unroll")
         return;
     }
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int m = m0 + wm * 64 + mi * 16 + fr;
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + row_base + mi * 16 + fr;
         if (m >= g.M) continue;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + wn * 64 + ni * 16 + fq * 4;
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + col_base + ni * 16 + fq * 4;
             if (n >= g.N) continue;
             float v[4] = {acc[ni][mi].x, acc[ni][mi].y, acc[ni][mi].z, acc[ni][mi].w};
 #pragma unroll
@@ -450,17 +519,19 @@ _Pragma("unroll")
     }
 }
 
+template <bool GATED, bool KTAIL>
 static int launch_big(const GemmArgs& a, hipStream_t st) {
     const size_t lds = (size_t)BG_BM * (BG_BN + 4) * 4;   // 67.6 KB: fp32 epilogue tile (>= the 64 KB of stage buffers)
     static bool attr_done = false;
     if (!attr_done) {
-        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_big<GATED, KTAIL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)lds));
         attr_done = true;
     }
     const int n_tiles = cdiv(a.N, BG_BN), m_tiles = cdiv(a.M, BG_BM);
     const long nwg = (long)n_tiles * m_tiles;
     MI355_REQUIRE(nwg < (1l << 31), "gemm: grid too large");
-    hipLaunchKernelGGL(k_gemm_big, dim3((unsigned)nwg), dim3(256), lds, st, a, n_tiles, (int)nwg);
+    hipLaunchKernelGGL((k_gemm_big<GATED, KTAIL>), dim3((unsigned)nwg), dim3(256), lds, st, a, n_tiles, (int)nwg);
     MI355_LAUNCH_CHECK();
     return OK;
 }
@@ -676,10 +747,17 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t st) {
     // Measured on MI355X (profiles/r01_effnet_per_op_*.txt): the 64-row / BK=64 variants lose to 128 x BN x 32
     // on every EfficientNet layer (each wave re-reads the whole W tile from LDS, so halving the rows per wave
     // makes the block LDS-bound); they stay instantiated for tiny-M problems (classifier, M = batch).
-    // compute-heavy shapes: DMA-staged 128x128x64 kernel (no gate / ReLU6 prologue there)
-    if (a.K % 64 == 0 && a.K >= 128 && a.N >= 96 && a.M >= 1024 && !a.gate && !a.a_relu6 && a.ldw >= a.K &&
-        ((uintptr_t)a.A % 16 == 0) && a.lda % 8 == 0)
-        return launch_big(a, st);
+    // K-deep shapes: DMA-staged 128x128x64 kernel (2.6x the register-staged kernel on the 7x7 projections:
+    // 21 us vs 55 us at M=12544, N=232, K=1392); gated / ReLU6'd A operands use the fragment-gating variant
+    if (a.zeros && a.K >= 128 && a.N >= 64 && a.M >= 1024 && ((uintptr_t)a.A % 16 == 0) && a.lda % 8 == 0 &&
+        (!a.gate || a.gate_ld >= a.K)) {
+        // 128-wide column tiles: skip when padding would waste > ~25 % of the tile (N = 136 -> 256 lost to the
+        // 144-wide register-staged tile: 0.065 vs 0.055 ms on 816->136 @14x14)
+        const bool fits = (long)a.N * 13 >= (long)cdiv(a.N, BG_BN) * BG_BN * 10;
+        const bool ktail = (a.K % 64 != 0) || (a.ldw % 64 != 0);
+        if ((a.gate || a.a_relu6) && fits) return ktail ? launch_big<true, true>(a, st) : launch_big<true, false>(a, st);
+        if (!a.gate && !a.a_relu6 && a.N >= 96) return ktail ? launch_big<false, true>(a, st) : launch_big<false, false>(a, st);
+    }
     // small-K layers are pure streaming (one or two K tiles): narrower tiles keep 4+ waves per SIMD resident
     static const int use_stream = getenv("MI355_GEMM_STREAM") ? atoi(getenv("MI355_GEMM_STREAM")) : 1;
     if (use_stream) {

@@ -236,6 +236,7 @@ static int exec_op(ExecCtx& cx, const Op& op) {
             a.out = cx.slot_ptr(op.out); a.ldo = op.cout; a.out_f32 = 0;
             a.M = cx.nb * hw; a.N = op.cout; a.K = op.cin;
             a.act = op.act; a.a_relu6 = op.a_relu6;
+            a.zeros = (const bf16_t*)cx.w(0);
             return launch_gemm_bf16(a, cx.st);
         }
         case OP_DW:
@@ -392,6 +393,7 @@ static int forward_impl(mi355_model* m, const float* x, int B, int H, int W, flo
             a.bias = (const float*)cx.w(c.b_off);
             a.out = out + (size_t)b0 * d.num_classes; a.ldo = d.num_classes; a.out_f32 = 1;
             a.M = nb; a.N = d.num_classes; a.K = c.cin; a.act = ACT_NONE; a.rows_per_img = 1; a.res_n = a.N;
+            a.zeros = (const bf16_t*)cx.w(0);
             if (int e = launch_gemm_bf16(a, st)) return e;
         }
     }
@@ -470,6 +472,7 @@ int mi355_model_set_tensor(mi355_model_t m, const char* name, const float* host_
 int mi355_model_pack(mi355_model_t m, void* stream) {
     MI355_REQUIRE(m, "pack: null model");
     m->blob.clear();
+    m->blob.resize(256, 0);   // zero page at offset 0 (source of out-of-range DMA chunks in k_gemm_big)
     Packer pk{m, m->blob};
     for (Op& op : m->def.ops)
         if (int e = pack_op(pk, op)) return e;
@@ -684,6 +687,12 @@ int mi355_gemm_bf16(const void* A, const void* W, const float* bias, void* out, 
     GemmArgs a{};
     a.A = (const bf16_t*)A; a.lda = K; a.W = (const bf16_t*)W; a.ldw = ldw; a.bias = bias;
     a.out = out; a.ldo = N; a.out_f32 = 0; a.M = M; a.N = N; a.K = K; a.act = act; a.rows_per_img = 1; a.res_n = N;
+    static void* zero_page = nullptr;   // one 256-byte zero page per process for the DMA kernel's out-of-range chunks
+    if (!zero_page) {
+        MI355_CHECK_HIP(hipMalloc(&zero_page, 256));
+        MI355_CHECK_HIP(hipMemset(zero_page, 0, 256));
+    }
+    a.zeros = (const bf16_t*)zero_page;
     return launch_gemm_bf16(a, (hipStream_t)stream);
 }
 

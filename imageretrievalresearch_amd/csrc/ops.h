@@ -20,6 +20,7 @@ struct GemmArgs {
     int M, N, K;
     int act;
     int a_relu6;
+    const bf16_t* zeros;   // >= 64 bytes of device zeros (source of out-of-range DMA chunks); null disables the DMA path
 };
 int launch_gemm_bf16(const GemmArgs& a, hipStream_t st);
 

@@ -5,7 +5,8 @@ import os, sys, time, torch
 import imageretrievalresearch_amd as M
 from imageretrievalresearch_amd._lib import lib, check, stream_ptr
 dev = "cuda:0"
-shapes = [(401408, 384, 128), (401408, 128, 128), (401408, 512, 128), (401408, 128, 512), (100352, 768, 256), (100352, 1024, 256), (25088, 1536, 512), (25088, 2048, 512), (25088, 512, 2048), (6272, 3072, 1024), (6272, 4096, 1024), (6272, 1024, 4096), (12544, 1536, 384), (50176, 96, 576),
+shapes = [(12544, 232, 1408), (12544, 232, 1392), (12544, 384, 2304), (50176, 136, 832), (50176, 136, 816), (50176, 96, 576),
+          (401408, 384, 128), (401408, 128, 128), (401408, 512, 128), (401408, 128, 512), (100352, 768, 256), (100352, 1024, 256), (25088, 1536, 512), (25088, 2048, 512), (25088, 512, 2048), (6272, 3072, 1024), (6272, 4096, 1024), (6272, 1024, 4096), (12544, 1536, 384), (50176, 96, 576),
           (12544, 1392, 232), (12544, 232, 1392), (50176, 576, 96), (50176, 96, 576), (50176, 816, 136), (50176, 136, 816),
           (802816, 192, 32), (802816, 32, 192), (3211264, 144, 24), (12544, 1536, 384), (12544, 192, 32), (12544, 192, 1392),
           (1568, 1392, 232), (128, 192, 32), (128, 192, 1392)]
