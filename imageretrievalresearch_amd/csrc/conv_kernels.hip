@@ -187,7 +187,9 @@ _Pragma("unroll")
             if (ox0 + p < Wo) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) psum[j] += acc[p][j];
-                *reinterpret_cast<u32x4*>(o + (size_t)p * C) = pack8(acc[p]);
+                // streaming store: the output is not re-read by this kernel, keep the L2 for the input rows that the
+                // neighbouring output rows are about to re-read
+                __builtin_nontemporal_store(pack8(acc[p]), reinterpret_cast<u32x4*>(o + (size_t)p * C));
             }
         }
     }
