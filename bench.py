@@ -168,7 +168,7 @@ def main():
         avg_ms = prof[fam]["ms"] / launches
         bytes_per_launch = tr["bytes_by_kind"][fam] / (launches / 3)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        kernel_names = {"gemm": "k_gemm_bf16 (1x1 conv)", "dw": "k_dwconv (depthwise + SE squeeze)",
+        kernel_names = {"gemm": "1x1-conv GEMM family: k_gemm_bf16 / k_gemm_big / k_gemm_stream", "dw": "k_dwconv (depthwise + SE squeeze)",
                         "fused": "k_fused_late (1x1 expand + depthwise + SE squeeze, expanded tensor in LDS)", "stem": "k_stem", "se": "k_se", "attn": "k_win_attn", "ln": "k_layernorm", "other": "other"}
         # HBM bytes per launch of that family from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in
         # separate runs, gfx950 x2 read correction) — cannot be collected from inside this process

@@ -434,7 +434,10 @@ __global__ __launch_bounds__(SE_THREADS) void k_se(const float* __restrict__ poo
         s[c] = a * inv_hw;
     }
     __syncthreads();
-    for (int j = wave; j < rd; j += SE_THREADS / 64) {
+    // every image's workgroup reads the same FC weights: rotate the starting row / column by the image index so the
+    // co-resident workgroups do not hit the same L2 lines in lock-step (outputs are independent: order is free)
+    for (int jj = wave; jj < rd; jj += SE_THREADS / 64) {
+        const int j = (jj + b) % rd;
         const float* wr = w1 + (size_t)j * C;
         float a = 0.f;
 #pragma unroll 4
@@ -443,7 +446,10 @@ __global__ __launch_bounds__(SE_THREADS) void k_se(const float* __restrict__ poo
         if (lane == 0) r[j] = apply_act(a + b1[j], act1);
     }
     __syncthreads();
-    for (int c = tid; c < C; c += SE_THREADS) {
+    const int rot = (b * 192) % C;
+    for (int cc = tid; cc < C; cc += SE_THREADS) {
+        int c = cc + rot;
+        if (c >= C) c -= C;
         float a = b2[c];
 #pragma unroll 8
         for (int j = 0; j < rd; ++j) a += w2t[(size_t)j * C + c] * r[j];

@@ -82,7 +82,11 @@ __global__ __launch_bounds__(FL_THREADS) void k_fused_late(const FusedArgs a) {
     const int strips = (a.Wo + PX - 1) / PX;
     const int nitems = CGC * strips * a.Ho;
 
-    for (int chunk = chunk0; chunk < chunk1; ++chunk) {
+    // Every workgroup needs every slab's weights; start each one at a different slab (rotated by image index) so the
+    // 256 co-resident workgroups do not stream the same W lines through the same L2 channels in lock-step.
+    const int nch = chunk1 - chunk0;
+    for (int ci = 0; ci < nch; ++ci) {
+        const int chunk = chunk0 + (ci + b) % nch;
         const int cbase = chunk * MC;
         // ---- phase 1: E slab = act(X W^T + b) -> Es (bf16)
         if (!(a.debug_skip & 1))
