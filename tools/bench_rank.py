@@ -1,0 +1,16 @@
+"""Rank-only timing: Q queries vs G x 1536 gallery, top-3 (developer tool)."""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+import time, torch
+import imageretrievalresearch_amd as M
+from imageretrievalresearch_amd import synth
+dev = "cuda:0"
+for Q, G in ((256, 100000), (256, 10000), (1, 100000), (64, 1000000)):
+    q = M.synth_fill(Q * 1536, 13, synth.NORMAL, dev).view(Q, 1536)
+    g = M.l2_normalize_rows(M.synth_fill(G * 1536, 5, synth.NORMAL, dev).view(G, 1536))
+    for _ in range(3): M.cosine_topk(q, g, 3, gallery_is_normalized=True)
+    torch.cuda.synchronize(); t = time.perf_counter(); n = 20
+    for _ in range(n): M.cosine_topk(q, g, 3, gallery_is_normalized=True)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
+    print(f"Q={Q} G={G}: {dt*1e3:.3f} ms  {Q/dt:.0f} q/s  {2.0*Q*G*1536/dt/1e12:.1f} TFLOP/s  {4.0*G*1536/dt/1e9:.0f} GB/s gallery stream")
+    del g
