@@ -155,6 +155,7 @@ def main():
         t_embed = timeit(lambda: model(x), n_side)
         q = M.synth_fill(a.batch * D, 13, synth.NORMAL, dev).view(a.batch, D)
         t_rank = timeit(lambda: gal.ops.local_topk(q, gal.local, TOPK, 0), n_side)
+        t_rank1 = timeit(lambda: gal.ops.local_topk(q[:1], gal.local, TOPK, 0), n_side)   # the reference's per-query call shape
 
         # ---- roofline of the dominant kernel family: hipEvents around every launch, on the launch stream
         model.set_option("profile", 1)
@@ -201,6 +202,8 @@ def main():
             "embed_roofline": {"algorithmic_GBps": embed_gbs, "frac_of_8TBps": embed_gbs / HBM_PEAK_GBS,
                                "act_MB_per_img": tr["act_bytes"] / a.batch / 1e6,
                                "gflop_per_img": 2 * tr["macs"] / a.batch / 1e9},
+            "rank_single_query": {"queries_per_s": 1.0 / t_rank1, "bound": "hbm",
+                                  "gallery_stream_GBps": 4.0 * (hi - lo) * D / t_rank1 / 1e9, "peak_GBps": HBM_PEAK_GBS},
             "rank_roofline": {"bound": "mfma-f32", "tflops": 2.0 * a.batch * (hi - lo) * D / t_rank / 1e12,
                               "peak_tflops": 157.3},
             "roofline": roofline,

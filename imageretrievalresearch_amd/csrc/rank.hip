@@ -200,6 +200,53 @@ __global__ __launch_bounds__(256) void k_cos_gemm(const float* __restrict__ Qn, 
 }
 
 // =====================================================================================
+// few queries (Q <= 4, the reference's own per-query call shape cos(q[None], G), train/train.py:250): a GEMM tile
+// would be 98 % padding; this is a GEMV, bound by streaming the gallery once (4*D bytes per row).  One wave per
+// gallery row (6 KB contiguous for D = 1536), the normalised queries sit in LDS, two rows in flight per wave.
+// =====================================================================================
+template <int NQ>
+__global__ __launch_bounds__(256) void k_cos_gemv(const float* __restrict__ Qn, const float* __restrict__ Gal,
+                                                  const float* __restrict__ ginv, float* __restrict__ S, i64 G, int D,
+                                                  int vec) {
+    extern __shared__ __attribute__((aligned(16))) float qs[];   // [NQ][D]
+    for (int i = threadIdx.x; i < NQ * D; i += 256) qs[i] = Qn[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const i64 wave_id = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const i64 nwaves = (i64)gridDim.x * 4;
+    for (i64 g = wave_id; g < G; g += nwaves) {
+        const float* row = Gal + g * D;
+        float acc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = 0.f;
+        if (vec) {
+            const f32x4* r4 = reinterpret_cast<const f32x4*>(row);
+#pragma unroll 2
+            for (int i = lane; i < D / 4; i += 64) {
+                const f32x4 v = r4[i];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const f32x4 u = *reinterpret_cast<const f32x4*>(&qs[q * D + i * 4]);
+                    acc[q] += v.x * u.x + v.y * u.y + v.z * u.z + v.w * u.w;
+                }
+            }
+        } else {
+            for (int i = lane; i < D; i += 64) {
+                const float v = row[i];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q] += v * qs[q * D + i];
+            }
+        }
+        const float gs = ginv ? ginv[g] : 1.0f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float t = wave_sum(acc[q]);
+            if (lane == 0) S[(i64)q * G + g] = t * gs;
+        }
+    }
+}
+
+// =====================================================================================
 // top-k selection
 // =====================================================================================
 __device__ __forceinline__ bool better(float a, i64 ia, float b, i64 ib) {
@@ -563,6 +610,15 @@ static int cos_gemm(const float* qn, const float* gal, const float* ginv, float*
                     hipStream_t st) {
     const bool vec = vec_ok(qn, D) && vec_ok(gal, D);
     const int q = (int)Q;
+    if (Q <= 4 && (size_t)Q * D * sizeof(float) <= 60 * 1024) {
+        const size_t lds = (size_t)Q * D * sizeof(float);
+        const unsigned blocks = (unsigned)(cdiv(G, 4) < 4096 ? cdiv(G, 4) : 4096);
+#define GEMV_LAUNCH(NQ) hipLaunchKernelGGL((k_cos_gemv<NQ>), dim3(blocks), dim3(256), lds, st, qn, gal, ginv, S, G, D, (int)vec)
+        if (Q == 1) GEMV_LAUNCH(1); else if (Q == 2) GEMV_LAUNCH(2); else if (Q == 3) GEMV_LAUNCH(3); else GEMV_LAUNCH(4);
+#undef GEMV_LAUNCH
+        MI355_LAUNCH_CHECK();
+        return OK;
+    }
     if (Q > 128) return vec ? launch_gemm<4, true>(qn, gal, ginv, S, q, G, D, st) : launch_gemm<4, false>(qn, gal, ginv, S, q, G, D, st);
     if (Q > 64) return vec ? launch_gemm<2, true>(qn, gal, ginv, S, q, G, D, st) : launch_gemm<2, false>(qn, gal, ginv, S, q, G, D, st);
     return vec ? launch_gemm<1, true>(qn, gal, ginv, S, q, G, D, st) : launch_gemm<1, false>(qn, gal, ginv, S, q, G, D, st);

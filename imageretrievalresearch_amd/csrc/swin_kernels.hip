@@ -269,34 +269,29 @@ __global__ __launch_bounds__(256) void k_win_attn(const bf16_t* __restrict__ qkv
         for (int j = 0; j < 8; ++j) Vt[(dp + j) * WA_VLD + key] = e[j];
     }
 
-    // ---- S^T = K Q^T : A rows = keys, B cols = queries, contraction over d (32 = one k-step)
-    bf16x8 kf[4], qf[4];
+    // ---- per query tile u: S^T = K Q^T (keys on the MFMA rows), bias + mask + softmax, O^T = V^T P^T, store.
+    // Working one 16-query tile at a time keeps ~90 VGPRs live (the all-at-once form needed 176 -> 2 waves/SIMD).
+    bf16x8 kf[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int i = t * 16 + fr;
-        u32x4 kv = {0u, 0u, 0u, 0u}, qv = {0u, 0u, 0u, 0u};
-        if (i < WA_N) {
-            const bf16_t* row = base + (size_t)token_of(i) * C3 + fq * 8;
-            qv = *reinterpret_cast<const u32x4*>(row);
-            kv = *reinterpret_cast<const u32x4*>(row + C);
-        }
+        u32x4 kv = {0u, 0u, 0u, 0u};
+        if (i < WA_N) kv = *reinterpret_cast<const u32x4*>(base + (size_t)token_of(i) * C3 + C + fq * 8);
         kf[t] = *reinterpret_cast<bf16x8*>(&kv);
-        qf[t] = *reinterpret_cast<bf16x8*>(&qv);
     }
-    f32x4 s[4][4];   // [key tile t][query tile u]; lane: query = 16u + fr, keys = 16t + 4*fq + r
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            s[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t], qf[u], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-
-    // ---- bias + mask + softmax over keys (in-lane 16 values, then across the 4 lane groups)
     const float* bh = bias + (size_t)h * WA_N * 64;
-    bf16x8 pf[4][2];   // [query tile u][k-step]: P^T in B-operand layout
-#pragma unroll
+#pragma unroll 1
     for (int u = 0; u < 4; ++u) {
         const int qi = u * 16 + fr;
         const int qc = qi < WA_N ? qi : WA_N - 1;     // clamp padded queries to a valid row (result discarded)
+        const int qtok = token_of(qc);
+        const u32x4 qv = *reinterpret_cast<const u32x4*>(base + (size_t)qtok * C3 + fq * 8);
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(&qv);
+        f32x4 s[4];   // [key tile t]; lane: query = 16u + fr, keys = 16t + 4*fq + r
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t], qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+
         const int ql = shift > 0 ? label_of(qc) : 0;
         float v[4][4];
         float mx = -INFINITY;
@@ -304,7 +299,7 @@ __global__ __launch_bounds__(256) void k_win_attn(const bf16_t* __restrict__ qkv
         for (int t = 0; t < 4; ++t) {
             const int k0 = t * 16 + fq * 4;
             const f32x4 bb = *reinterpret_cast<const f32x4*>(bh + (size_t)qc * 64 + k0);
-            const float sv[4] = {s[t][u].x, s[t][u].y, s[t][u].z, s[t][u].w};
+            const float sv[4] = {s[t].x, s[t].y, s[t].z, s[t].w};
             const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -323,12 +318,13 @@ __global__ __launch_bounds__(256) void k_win_attn(const bf16_t* __restrict__ qkv
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                v[t][r] = __expf(v[t][r] - mx);
+                v[t][r] = __builtin_amdgcn_exp2f((v[t][r] - mx) * 1.4426950408889634f);
                 sum += v[t][r];
             }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
+        const float inv = __builtin_amdgcn_rcpf(sum);
+        bf16x8 pf[2];   // P^T in B-operand layout for the two 32-key k-steps
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             u32x4 pk;
@@ -336,45 +332,34 @@ __global__ __launch_bounds__(256) void k_win_attn(const bf16_t* __restrict__ qkv
             pk.y = pack2bf(v[2 * ks][2] * inv, v[2 * ks][3] * inv);
             pk.z = pack2bf(v[2 * ks + 1][0] * inv, v[2 * ks + 1][1] * inv);
             pk.w = pack2bf(v[2 * ks + 1][2] * inv, v[2 * ks + 1][3] * inv);
-            pf[u][ks] = *reinterpret_cast<bf16x8*>(&pk);
+            pf[ks] = *reinterpret_cast<bf16x8*>(&pk);
         }
-    }
 
-    // ---- O^T = V^T P^T : A rows = d (two 16-row tiles), k = keys in the SAME permuted order as pf:
-    // element j of lane group fq in k-step ks is key 16*(2ks + (j>>2)) + 4*fq + (j&3)
-    f32x4 o[2][4];
+        // O^T = V^T P^T : A rows = d (two 16-row tiles), k = keys in the SAME permuted order as pf:
+        // element j of lane group fq in k-step ks is key 16*(2ks + (j>>2)) + 4*fq + (j&3)
+        f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-    for (int vt = 0; vt < 2; ++vt)
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) o[vt][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int vt = 0; vt < 2; ++vt) {
-            const bf16_t* vr = Vt + (vt * 16 + fr) * WA_VLD + 32 * ks + 4 * fq;
-            u32x4 a;
-            const u32x2 lo = *reinterpret_cast<const u32x2*>(vr);
-            const u32x2 hi = *reinterpret_cast<const u32x2*>(vr + 16);
-            a.x = lo.x; a.y = lo.y; a.z = hi.x; a.w = hi.y;
-            const bf16x8 af = *reinterpret_cast<bf16x8*>(&a);
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                o[vt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, pf[u][ks], o[vt][u], 0, 0, 0);
+            for (int vt = 0; vt < 2; ++vt) {
+                const bf16_t* vr = Vt + (vt * 16 + fr) * WA_VLD + 32 * ks + 4 * fq;
+                u32x4 a;
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(vr);
+                const u32x2 hi = *reinterpret_cast<const u32x2*>(vr + 16);
+                a.x = lo.x; a.y = lo.y; a.z = hi.x; a.w = hi.y;
+                o[vt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&a), pf[ks], o[vt], 0, 0, 0);
+            }
         }
-    }
-
-    // ---- store: lane holds query 16u + fr, d = 16vt + 4*fq + r
+        // store: lane holds query 16u + fr, d = 16vt + 4*fq + r
+        if (qi < WA_N) {
+            bf16_t* orow = out + ((size_t)b * L + qtok) * C + h * 32 + fq * 4;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int qi = u * 16 + fr;
-        if (qi >= WA_N) continue;
-        bf16_t* orow = out + ((size_t)b * L + token_of(qi)) * C + h * 32 + fq * 4;
-#pragma unroll
-        for (int vt = 0; vt < 2; ++vt) {
-            u32x2 w;
-            w.x = pack2bf(o[vt][u].x, o[vt][u].y);
-            w.y = pack2bf(o[vt][u].z, o[vt][u].w);
-            *reinterpret_cast<u32x2*>(orow + vt * 16) = w;
+            for (int vt = 0; vt < 2; ++vt) {
+                u32x2 w;
+                w.x = pack2bf(o[vt].x, o[vt].y);
+                w.y = pack2bf(o[vt].z, o[vt].w);
+                *reinterpret_cast<u32x2*>(orow + vt * 16) = w;
+            }
         }
     }
 }
