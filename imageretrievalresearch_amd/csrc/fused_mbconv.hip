@@ -61,19 +61,31 @@ __global__ __launch_bounds__(FL_THREADS) void k_fused_late(const FusedArgs a) {
     const int chunk0 = blockIdx.x * cpb;
     const int chunk1 = min(nchunks, chunk0 + cpb);
 
-    // ---- phase 0: X[b] -> LDS (zero fill for k >= Cin and rows >= P)
+    // ---- phase 0: X[b] -> LDS (zero fill for k >= Cin and rows >= P).  Four 16-byte loads are issued per thread
+    // before the first LDS store (one load in flight per thread left the whole CU waiting on HBM latency 8 times over).
     {
         const int kc = a.Kp >> 3;
         const bf16_t* xb = a.X + (size_t)b * P * a.Cin;
-        for (int id = tid; id < MT * 16 * kc; id += FL_THREADS) {
-            const int row = id / kc, c = id - row * kc;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (row < P && c * 8 < a.Cin) v = *reinterpret_cast<const u32x4*>(xb + (size_t)row * a.Cin + c * 8);
-            *reinterpret_cast<u32x4*>(&Xs[row * XLD + c * 8]) = v;
-        }
+        const int total = MT * 16 * kc;
+        constexpr int U = 4;
         // zero the whole E image once: the pad columns are never written again
         for (int id = tid; id < EP * (ELD / 8); id += FL_THREADS)
             *reinterpret_cast<u32x4*>(&Es[(size_t)id * 8]) = (u32x4){0u, 0u, 0u, 0u};
+        for (int id0 = tid; id0 < total; id0 += FL_THREADS * U) {
+            u32x4 v[U];
+            int dst[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int id = id0 + u * FL_THREADS;
+                const int row = id / kc, c = id - row * kc;
+                v[u] = (u32x4){0u, 0u, 0u, 0u};
+                dst[u] = id < total ? row * XLD + c * 8 : -1;
+                if (id < total && row < P && c * 8 < a.Cin) v[u] = *reinterpret_cast<const u32x4*>(xb + (size_t)row * a.Cin + c * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (dst[u] >= 0) *reinterpret_cast<u32x4*>(&Xs[dst[u]]) = v[u];
+        }
     }
     __syncthreads();
 
@@ -223,14 +235,27 @@ _Pragma("unroll")
             }
         }
         if (a.pool != nullptr) {
+            // lanes l, l+CGC, l+2*CGC.. of a wave hold the same channel group: fold them with shuffles (fixed order),
+            // then one LDS pass over the 8 per-wave partials.
 #pragma unroll
-            for (int j = 0; j < 8; ++j) red[tid * 8 + j] = psum[j];
+            for (int o = 32; o >= CGC; o >>= 1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) psum[j] += __shfl_xor(psum[j], o, 64);
+            }
+            constexpr int LPW = CGC < 64 ? CGC : 64;          // distinct channel groups per wave
+            if (lane < LPW) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) red[(wave * LPW + lane) * 8 + j] = psum[j];
+            }
             __syncthreads();
             if (tid < CGC && cbase + tid * 8 < a.mid) {
                 float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                for (int u = tid; u < FL_THREADS; u += CGC) {   // same channel group, thread order
+                if constexpr (CGC <= 64) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) s[j] += red[u * 8 + j];
+                    for (int w = 0; w < FL_THREADS / 64; ++w) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) s[j] += red[(w * LPW + tid) * 8 + j];
+                    }
                 }
                 float* pp = a.pool + (size_t)b * a.mid + cbase + tid * 8;
                 *reinterpret_cast<f32x4*>(pp) = (f32x4){s[0], s[1], s[2], s[3]};

@@ -10,6 +10,8 @@ shapes = [(12544, 232, 1408), (12544, 232, 1392), (12544, 384, 2304), (50176, 13
           (12544, 1392, 232), (12544, 232, 1392), (50176, 576, 96), (50176, 96, 576), (50176, 816, 136), (50176, 136, 816),
           (802816, 192, 32), (802816, 32, 192), (3211264, 144, 24), (12544, 1536, 384), (12544, 192, 32), (12544, 192, 1392),
           (1568, 1392, 232), (128, 192, 32), (128, 192, 1392)]
+if os.environ.get("SHAPES"):
+    shapes = [tuple(int(v) for v in t.split("x")) for t in os.environ["SHAPES"].split(",")]
 for (Mm, N, K) in shapes:
     ldw = (K + 31) // 32 * 32
     Np = (N + 15) // 16 * 16
