@@ -134,6 +134,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    torch.cuda.synchronize()   # inputs / gallery were built on the default stream
     for _ in range(a.warmup):
         step()
     sync_all()
