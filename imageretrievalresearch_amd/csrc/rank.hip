@@ -64,21 +64,22 @@ static inline int vec_ok(const void* p, int dim) { return (dim % 4 == 0) && (((u
 // cosine GEMM:  S[q][g] = sum_d Qn[q][d] * Gal[g][d] * (ginv ? ginv[g] : 1)
 // =====================================================================================
 // Block = 4 waves as 2(M) x 2(N); wave tile = (MT*32) queries x 64 gallery rows; block tile =
-// (64*MT) x 128, BK = 32.  Both operands are "row x k-contiguous", so they share one LDS image:
-// [rows][36] floats (32 + 4 pad: ds_read_b128 of 16 distinct rows is bank-conflict free).
+// (64*MT) x 128 x BK.  Both operands are "row x k-contiguous", so they share one LDS image:
+// [rows][BK + 4] floats (the 4-float pad makes ds_read_b128 of 16 distinct rows bank-conflict free).
 // Per lane a float4 at k = 8t + 4*(lane>>5) feeds four 32x32x2 k-steps; A and B use the same k
 // permutation, which only reorders the (exact) fma chain.
-constexpr int RK_BK = 32;
-constexpr int RK_LD = 36;
 constexpr int RK_BN = 128;
 
-template <int MT, bool VEC>
+template <int MT, int RK_BK, bool VEC>
 __global__ __launch_bounds__(256) void k_cos_gemm(const float* __restrict__ Qn, const float* __restrict__ Gal,
                                                   const float* __restrict__ ginv, float* __restrict__ S,
                                                   int Q, i64 G, int D) {
     constexpr int BM = 64 * MT;
-    constexpr int A_LOADS = BM / 32;      // float4 loads per thread per K-tile for A
-    constexpr int B_LOADS = RK_BN / 32;   // 4
+    constexpr int RK_LD = RK_BK + 4;      // +4 floats: ds_read_b128 of 16 distinct rows is bank-conflict free (36 and 20)
+    constexpr int CPR = RK_BK / 4;        // float4 columns per row of a K-tile
+    constexpr int RPP = 256 / CPR;        // rows covered by one pass of the 256 threads
+    constexpr int A_LOADS = BM / RPP;     // float4 loads per thread per K-tile for A
+    constexpr int B_LOADS = RK_BN / RPP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                          // [2][BM][RK_LD]
     float* Bs = smem + 2 * BM * RK_LD;         // [2][RK_BN][RK_LD]
@@ -90,8 +91,8 @@ __global__ __launch_bounds__(256) void k_cos_gemm(const float* __restrict__ Qn, 
     const i64 n0 = (i64)blockIdx.x * RK_BN;
     const int m0 = blockIdx.y * BM;
 
-    const int c4 = tid & 7;    // float4 column within the 32-float K-tile
-    const int r0 = tid >> 3;   // 0..31
+    const int c4 = tid % CPR;  // float4 column within the K-tile
+    const int r0 = tid / CPR;
 
     f32x16 acc[MT][2];
 #pragma unroll
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void k_cos_gemm(const float* __restrict__ Qn, 
         const int k = k0 + c4 * 4;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            const int row = m0 + r0 + 32 * i;
+            const int row = m0 + r0 + RPP * i;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (row < Q) {
                 const float* p = Qn + (i64)row * D + k;
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void k_cos_gemm(const float* __restrict__ Qn, 
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
-            const i64 row = n0 + r0 + 32 * i;
+            const i64 row = n0 + r0 + RPP * i;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (row < G) {
                 const float* p = Gal + row * D + k;
@@ -145,10 +146,10 @@ __global__ __launch_bounds__(256) void k_cos_gemm(const float* __restrict__ Qn, 
         float* b = Bs + buf * RK_BN * RK_LD;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i)
-            *reinterpret_cast<f32x4*>(a + (r0 + 32 * i) * RK_LD + c4 * 4) = ra[i];
+            *reinterpret_cast<f32x4*>(a + (r0 + RPP * i) * RK_LD + c4 * 4) = ra[i];
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i)
-            *reinterpret_cast<f32x4*>(b + (r0 + 32 * i) * RK_LD + c4 * 4) = rb[i];
+            *reinterpret_cast<f32x4*>(b + (r0 + RPP * i) * RK_LD + c4 * 4) = rb[i];
     };
 
     const int nt = (D + RK_BK - 1) / RK_BK;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void k_cos_gemm(const float* __restrict__ Qn, 
         const float* a = As + buf * BM * RK_LD + (wm * MT * 32 + lr) * RK_LD + lk;
         const float* b = Bs + buf * RK_BN * RK_LD + (wn * 64 + lr) * RK_LD + lk;
 #pragma unroll
-        for (int t8 = 0; t8 < 4; ++t8) {
+        for (int t8 = 0; t8 < RK_BK / 8; ++t8) {
             f32x4 af[MT], bfr[2];
 #pragma unroll
             for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * RK_LD + t8 * 8);
@@ -589,19 +590,19 @@ static RankWs carve(void* ws, i64 Q, i64 G, int D, int k, bool need_ginv, bool n
     return r;
 }
 
-template <int MT, bool VEC>
+template <int MT, int BK, bool VEC>
 static int launch_gemm(const float* qn, const float* gal, const float* ginv, float* S, int Q, i64 G, int D,
                        hipStream_t st) {
     constexpr int BM = 64 * MT;
-    const size_t lds = (size_t)2 * (BM + RK_BN) * RK_LD * sizeof(float);
+    const size_t lds = (size_t)2 * (BM + RK_BN) * (BK + 4) * sizeof(float);
     static bool attr_done = false;  // per instantiation
     if (!attr_done) {
-        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_cos_gemm<MT, VEC>,
+        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_cos_gemm<MT, BK, VEC>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     dim3 grid((unsigned)cdiv(G, RK_BN), (unsigned)cdiv(Q, BM));
-    hipLaunchKernelGGL((k_cos_gemm<MT, VEC>), grid, dim3(256), lds, st, qn, gal, ginv, S, Q, G, D);
+    hipLaunchKernelGGL((k_cos_gemm<MT, BK, VEC>), grid, dim3(256), lds, st, qn, gal, ginv, S, Q, G, D);
     MI355_LAUNCH_CHECK();
     return OK;
 }
@@ -619,9 +620,12 @@ static int cos_gemm(const float* qn, const float* gal, const float* ginv, float*
         MI355_LAUNCH_CHECK();
         return OK;
     }
-    if (Q > 128) return vec ? launch_gemm<4, true>(qn, gal, ginv, S, q, G, D, st) : launch_gemm<4, false>(qn, gal, ginv, S, q, G, D, st);
-    if (Q > 64) return vec ? launch_gemm<2, true>(qn, gal, ginv, S, q, G, D, st) : launch_gemm<2, false>(qn, gal, ginv, S, q, G, D, st);
-    return vec ? launch_gemm<1, true>(qn, gal, ginv, S, q, G, D, st) : launch_gemm<1, false>(qn, gal, ginv, S, q, G, D, st);
+    // Tile choice, measured on MI355X (tools/bench_rank.py, D = 1536): the exact-fp32 MFMA loop plateaus at 95-110 TFLOP/s
+    // for every tile shape, so what differs is the partial last round of tiles.  128-query tiles with BK = 16 keep two
+    // workgroups (41 KB of LDS each) on a CU: a lone workgroup in the last round runs at full speed, which halves the
+    // wave-quantisation loss (Q = 256, G = 100k: 0.83 ms, against 0.95 ms with 256 x 128 tiles, one per CU).
+    if (Q > 64) return vec ? launch_gemm<2, 16, true>(qn, gal, ginv, S, q, G, D, st) : launch_gemm<2, 16, false>(qn, gal, ginv, S, q, G, D, st);
+    return vec ? launch_gemm<1, 32, true>(qn, gal, ginv, S, q, G, D, st) : launch_gemm<1, 32, false>(qn, gal, ginv, S, q, G, D, st);
 }
 
 static int check_rank_args(const float* queries, i64 Q, const float* gallery, i64 G, int dim) {

@@ -5,7 +5,11 @@ import time, torch
 import imageretrievalresearch_amd as M
 from imageretrievalresearch_amd import synth
 dev = "cuda:0"
-for Q, G in ((256, 100000), (256, 10000), (1, 100000), (64, 1000000)):
+import os
+cases = ((256, 100000), (256, 10000), (1, 100000), (64, 1000000))
+if os.environ.get("CASES"):
+    cases = [tuple(int(v) for v in c.split("x")) for c in os.environ["CASES"].split(",")]
+for Q, G in cases:
     q = M.synth_fill(Q * 1536, 13, synth.NORMAL, dev).view(Q, 1536)
     g = M.l2_normalize_rows(M.synth_fill(G * 1536, 5, synth.NORMAL, dev).view(G, 1536))
     for _ in range(3): M.cosine_topk(q, g, 3, gallery_is_normalized=True)
