@@ -751,9 +751,10 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t st) {
     // 21 us vs 55 us at M=12544, N=232, K=1392); gated / ReLU6'd A operands use the fragment-gating variant
     if (a.zeros && a.K >= 128 && a.N >= 64 && a.M >= 1024 && ((uintptr_t)a.A % 16 == 0) && a.lda % 8 == 0 &&
         (!a.gate || a.gate_ld >= a.K)) {
-        // 128-wide column tiles: skip when padding would waste > ~25 % of the tile (N = 136 -> 256 lost to the
-        // 144-wide register-staged tile: 0.065 vs 0.055 ms on 816->136 @14x14)
-        const bool fits = (long)a.N * 13 >= (long)cdiv(a.N, BG_BN) * BG_BN * 10;
+        // 128-wide column tiles for the gated variant: one tile needs N >= 72, several need < ~37 % padding
+        // (measured: N = 136 -> 256 loses to the 144-wide register-staged tile, 0.065 vs 0.055 ms on 816->136 @14x14;
+        //  N = 77..96 and 167..280 win: rexnet_200 GEMM time 3.96 -> 3.79 ms, efficientnet_b3a 2.35 -> 2.31 ms)
+        const bool fits = a.N <= BG_BN ? a.N >= 72 : (long)a.N * 16 >= (long)cdiv(a.N, BG_BN) * BG_BN * 10;
         const bool ktail = (a.K % 64 != 0) || (a.ldw % 64 != 0);
         if ((a.gate || a.a_relu6) && fits) return ktail ? launch_big<true, true>(a, st) : launch_big<true, false>(a, st);
         if (!a.gate && !a.a_relu6 && a.N >= 96) return ktail ? launch_big<false, true>(a, st) : launch_big<false, false>(a, st);
