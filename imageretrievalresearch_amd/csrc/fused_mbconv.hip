@@ -101,64 +101,73 @@ __global__ __launch_bounds__(FL_THREADS) void k_fused_late(const FusedArgs a) {
         const int chunk = chunk0 + (ci + b) % nch;
         const int cbase = chunk * MC;
         // ---- phase 1: E slab = act(X W^T + b) -> Es (bf16)
+        // Wave layout: CW channel tiles (16 channels each) per wave x all pixels (NIW >= 2), or - for the one-image
+        // case - 2 channel tiles x half of the pixel tiles, so that every A fragment read from LDS feeds two MFMAs
+        // (with one channel tile per wave the eight waves re-read the whole X image 8x and phase 1 was LDS-bound).
+        constexpr int CW = NIW == 1 ? 2 : NIW;              // channel tiles per wave
+        constexpr int MSPLIT = NIW == 1 ? 2 : 1;            // pixel-tile halves
+        constexpr int MTW = (MTP + MSPLIT - 1) / MSPLIT;    // pixel tiles per wave and pass
+        const int cw = NIW == 1 ? (wave & 3) : wave;        // which group of CW channel tiles
+        const int mh = NIW == 1 ? (wave >> 2) : 0;          // which half of the pixel tiles
         if (!(a.debug_skip & 1))
-        for (int mb = 0; mb < MT; mb += MTP) {
-            f32x4 acc[NIW][MTP];
+        for (int mb0 = 0; mb0 < MT; mb0 += MTP) {
+            const int mb = mb0 + mh * MTW;
+            f32x4 acc[CW][MTW];
 #pragma unroll
-            for (int j = 0; j < NIW; ++j)
+            for (int j = 0; j < CW; ++j)
 #pragma unroll
-                for (int m = 0; m < MTP; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const bf16_t* wrow[NIW];
-            bool wok[NIW];
+                for (int m = 0; m < MTW; ++m) acc[j][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const bf16_t* wrow[CW];
+            bool wok[CW];
 #pragma unroll
-            for (int j = 0; j < NIW; ++j) {
-                const int n = cbase + (wave * NIW + j) * 16 + fr;
+            for (int j = 0; j < CW; ++j) {
+                const int n = cbase + (cw * CW + j) * 16 + fr;
                 wok[j] = n < midp;
                 wrow[j] = a.We + (size_t)(wok[j] ? n : 0) * a.Kp + fk;
             }
-            u32x4 wnext[NIW];
+            u32x4 wnext[CW];
 #pragma unroll
-            for (int j = 0; j < NIW; ++j) wnext[j] = wok[j] ? *reinterpret_cast<const u32x4*>(wrow[j]) : (u32x4){0u, 0u, 0u, 0u};
+            for (int j = 0; j < CW; ++j) wnext[j] = wok[j] ? *reinterpret_cast<const u32x4*>(wrow[j]) : (u32x4){0u, 0u, 0u, 0u};
             for (int ks = 0; ks < a.Kp; ks += 32) {
-                bf16x8 wf[NIW];
+                bf16x8 wf[CW];
 #pragma unroll
-                for (int j = 0; j < NIW; ++j) {
+                for (int j = 0; j < CW; ++j) {
                     wf[j] = *reinterpret_cast<bf16x8*>(&wnext[j]);
                     // prefetch the next k-step's W fragment while this step's MFMAs run
                     if (ks + 32 < a.Kp && wok[j]) wnext[j] = *reinterpret_cast<const u32x4*>(wrow[j] + ks + 32);
                 }
 #pragma unroll
-                for (int m = 0; m < MTP; ++m) {
-                    if (mb + m < MT) {
+                for (int m = 0; m < MTW; ++m) {
+                    if (mb + m < MT && mh * MTW + m < MTP) {
                         const bf16x8 af = *reinterpret_cast<const bf16x8*>(&Xs[((mb + m) * 16 + fr) * XLD + ks + fk]);
 #pragma unroll
-                        for (int j = 0; j < NIW; ++j)
+                        for (int j = 0; j < CW; ++j)
                             acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af, acc[j][m], 0, 0, 0);
                     }
                 }
             }
             MI355_ACT_DISPATCH(a.act_e, {
 _Pragma("unroll")
-                for (int j = 0; j < NIW; ++j) {
-                    const int n = cbase + (wave * NIW + j) * 16 + (lane >> 4) * 4;
+                for (int j = 0; j < CW; ++j) {
+                    const int n = cbase + (cw * CW + j) * 16 + (lane >> 4) * 4;
                     f32x4 bb = {0.f, 0.f, 0.f, 0.f};
                     if (n < midp) bb = *reinterpret_cast<const f32x4*>(a.be + n);
 _Pragma("unroll")
-                    for (int m = 0; m < MTP; ++m) {
+                    for (int m = 0; m < MTW; ++m) {
                         acc[j][m].x = act_c<ACT>(acc[j][m].x + bb.x); acc[j][m].y = act_c<ACT>(acc[j][m].y + bb.y);
                         acc[j][m].z = act_c<ACT>(acc[j][m].z + bb.z); acc[j][m].w = act_c<ACT>(acc[j][m].w + bb.w);
                     }
                 }
             })
 #pragma unroll
-            for (int m = 0; m < MTP; ++m) {
+            for (int m = 0; m < MTW; ++m) {
                 const int p = (mb + m) * 16 + fr;          // this lane's pixel
-                if (mb + m < MT && p < P) {
+                if (mb + m < MT && mh * MTW + m < MTP && p < P) {
                     const int y = p / a.W;
                     const int erow = y * EW + (p - y * a.W) + PAD;
 #pragma unroll
-                    for (int j = 0; j < NIW; ++j) {
-                        const int nl = (wave * NIW + j) * 16 + (lane >> 4) * 4;   // channel within the slab
+                    for (int j = 0; j < CW; ++j) {
+                        const int nl = (cw * CW + j) * 16 + (lane >> 4) * 4;   // channel within the slab
                         u32x2 o;
                         o.x = pack2bf(acc[j][m].x, acc[j][m].y);
                         o.y = pack2bf(acc[j][m].z, acc[j][m].w);
