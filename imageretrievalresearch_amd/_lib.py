@@ -59,6 +59,8 @@ PROTOTYPES = {
     "mi355_gemm_bf16": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mi355_square_pad_normalize": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp]),
     "mi355_conv_input_silu": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "mi355_resize_bilinear_u8": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]),
+    "mi355_score_boost": (C.c_int, [vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int, vp, vp]),
 }
 
 _lib = None

@@ -287,6 +287,29 @@ def distinct_class_topn(idx: torch.Tensor, val: torch.Tensor, gallery_cls: torch
     return oc, oi, ov
 
 
+def _score_boost(score, eps, alpha, threshold, mode):
+    s = _f32c(score, "score")
+    out = torch.empty_like(s)
+    if s.numel():
+        with torch.cuda.device(s.device):
+            check(lib().mi355_score_boost(s.data_ptr(), s.numel(), float(eps), float(alpha), float(threshold), mode,
+                                          out.data_ptr(), stream_ptr(s.device)))
+    return out
+
+
+def cos_sim_score_with_threshold(score: torch.Tensor, eps: float, alpha: float, threshold: float) -> torch.Tensor:
+    """utils/score_booster.py:1-20 over a whole fp32 score tensor (the reference takes one score at a time and
+    prints it; the print is not reproduced)."""
+    return _score_boost(score, eps, alpha, threshold, 0)
+
+
+def cos_sim_score_booster(score: torch.Tensor, eps: float, alpha: float, mode: str) -> torch.Tensor:
+    """utils/score_booster.py:22-37; ``mode`` is "for_pos" or "for_neg" (anything else returns None there; here it raises)."""
+    if mode not in ("for_pos", "for_neg"):
+        raise MI355Error(f'cos_sim_score_booster: mode must be "for_pos" or "for_neg", got {mode!r}')
+    return _score_boost(score, eps, alpha, 0.0, 1 if mode == "for_pos" else 2)
+
+
 class Gallery:
     """Resident gallery: rows are L2-normalised once when added and stay in HBM as fp32 (SURVEY §8e:
     the gallery is *born* on the GPU that embedded it).  ``search`` is then one fused call per query

@@ -190,6 +190,19 @@ int mi355_gemm_bf16(const void* A, const void* W, const float* bias, void* out, 
 int mi355_square_pad_normalize(const unsigned char* img, int h, int w, int fill, const float* mean, const float* stdv,
                                float* out, void* stream);
 
+/* Training-time resize: transforms.Resize((out_h, out_w)) of train/train.py:48-50 applied to a PIL
+ * image, i.e. PIL.Image.resize((out_w, out_h), BILINEAR) — Pillow's two-pass antialiased resample (Resample.c, 8-bit
+ * path), reproduced bit-exactly.  img / out: uint8 RGB HWC on the device; tmp: device scratch of h * out_w * 3 bytes,
+ * needed only when both sides change (may be NULL otherwise). */
+int mi355_resize_bilinear_u8(const unsigned char* img, int h, int w, unsigned char* out, int out_h, int out_w,
+                             unsigned char* tmp, void* stream);
+
+/* Score booster (utils/score_booster.py:1-37) over n fp32 scores on the device.
+ * mode 0: cos_sim_score_with_threshold (score >= threshold ? (s+eps)/(eps+alpha) : |(s+alpha/eps)/(2 eps)|),
+ * mode 1: cos_sim_score_booster(mode="for_pos"), mode 2: mode="for_neg".  out may alias scores. */
+int mi355_score_boost(const float* scores, int64_t n, float eps, float alpha, float threshold, int mode, float* out,
+                      void* stream);
+
 /* conv_input pre-stem (inference/inference.py:103-105): out = SiLU(Conv2d(3,3,3,1,1,bias=False)(x)),
  * x/out [B][3][H][W] fp32 NCHW, w [3][3][3][3] fp32 (device). */
 int mi355_conv_input_silu(const float* x, const float* w, int B, int H, int W, float* out, void* stream);

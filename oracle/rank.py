@@ -136,3 +136,16 @@ def score_boost(score: np.ndarray, eps: float, alpha: float, mode: str) -> np.nd
     if mode == "for_neg":
         return np.abs((score + np.float32(alpha / eps)) / np.float32(2 * eps)).astype(np.float32)
     raise ValueError(mode)
+
+
+def score_boost(score: np.ndarray, eps: float, alpha: float, threshold: float = 0.0, mode: str = "threshold") -> np.ndarray:
+    """utils/score_booster.py:17-20 (mode "threshold") and :33-36 ("for_pos" / "for_neg"), elementwise in fp32."""
+    s = np.asarray(score, np.float32)
+    e, a = np.float32(eps), np.float32(alpha)
+    pos = (s + e) / (e + a)
+    neg = np.abs((s + (a / e)) / (np.float32(2.0) * e))
+    if mode == "for_pos":
+        return pos.astype(np.float32)
+    if mode == "for_neg":
+        return neg.astype(np.float32)
+    return np.where(s >= np.float32(threshold), pos, neg).astype(np.float32)

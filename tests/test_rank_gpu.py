@@ -207,3 +207,24 @@ def test_cosine_embedding_loss_and_validation_metrics():
     assert m["top1"].item() == pytest.approx(top1 / 48) and m["top3"].item() == pytest.approx(top3 / 48)
     assert m["cos_sims"].item() == pytest.approx(cos(tq, tp).mean().item(), abs=1e-5)
     assert m["cos_unsims"].item() == pytest.approx(cos(tq, tn).mean().item(), abs=1e-5)
+
+
+def test_score_booster_matches_reference_formulas():
+    """utils/score_booster.py:1-37 over a whole tensor (reference: one python float at a time); fp32, same op order."""
+    s = np.linspace(-0.2, 1.0, 1001, dtype=np.float32)
+    t = torch.from_numpy(s).to(DEV)
+    eps, alpha, thr = 0.3, 0.7, 0.55
+    got = M.cos_sim_score_with_threshold(t, eps, alpha, thr).cpu().numpy()
+    np.testing.assert_array_equal(got, orank.score_boost(s, eps, alpha, thr))
+    np.testing.assert_array_equal(M.cos_sim_score_booster(t, eps, alpha, "for_pos").cpu().numpy(),
+                                  orank.score_boost(s, eps, alpha, mode="for_pos"))
+    np.testing.assert_array_equal(M.cos_sim_score_booster(t, eps, alpha, "for_neg").cpu().numpy(),
+                                  orank.score_boost(s, eps, alpha, mode="for_neg"))
+    # the published formulas in double on a few points (what the reference computes for python floats)
+    for v in (0.1, 0.55, 0.9):
+        want = (v + eps) / (eps + alpha) if v >= thr else abs((v + (alpha / eps)) / (2 * eps))
+        g = float(M.cos_sim_score_with_threshold(torch.tensor([v], device=DEV), eps, alpha, thr)[0])
+        assert abs(g - want) < 1e-6 * max(1.0, abs(want))
+    with pytest.raises(M.MI355Error):
+        M.cos_sim_score_booster(t, eps, alpha, "sideways")
+    assert M.cos_sim_score_with_threshold(t[:0], eps, alpha, thr).shape == (0,)
