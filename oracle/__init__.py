@@ -15,4 +15,11 @@ Pinning status:
   reference nor installed here, and the reference holds no test or fixture for it.  The
   restatement follows timm 0.4.12's published structure and is anchored by exact parameter
   counts (efficientnet_b3 12 233 232; rexnet_150/200 9.73 M / 16.37 M; swin_base 87.77 M — see each module).
+* pre-processing (``oracle.preprocess``): the Resize of train/train.py:48 is PINNED against Pillow itself (the
+  third-party library torchvision calls for PIL images; Pillow 12.2.0 is installed here) in
+  ``tests/test_preprocess.py`` and by ``tests/golden/resize_golden.npz`` (``make_resize_golden.py``); SquarePad is
+  checked against ``PIL.ImageOps.expand``; ToTensor / Normalize are single-rounding fp32 formulas, unpinned against
+  torchvision (not installed).
+* score booster (``oracle.rank.score_boost``): the three published formulas of utils/score_booster.py, also checked in
+  double on sample points in the GPU test.
 """
