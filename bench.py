@@ -220,7 +220,7 @@ def main():
                               "peak_tflops": 157.3},
             "roofline": roofline,
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:   # the host-core baseline is reported at N=1 only
             result["cpu_baseline"] = cpu_baseline(a.model, a.gallery)
     if world > 1:
         dist.barrier()
