@@ -539,7 +539,7 @@ static size_t fused_lds_bytes(int H, int W, int Kp, int MC, int k, int stride) {
 bool fused_late_supported(int H, int W, int Cin, int mid, int k, int stride) {
     if (H * W > 208 || Cin % 8 || mid % 8) return false;
     if (!((k == 3 || k == 5) && (stride == 1 || stride == 2))) return false;
-    const int P = H * W, MT = (P + 15) / 16;
+    const int P = H * W;
     const int niw = P <= 64 ? 4 : (P <= 112 ? 2 : 1);
     const int Kp = (Cin + 31) & ~31;
     return fused_lds_bytes(H, W, Kp, 128 * niw, k, stride) <= 160 * 1024;

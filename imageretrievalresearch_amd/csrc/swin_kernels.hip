@@ -445,8 +445,6 @@ int swin_pack(Packer& pk, Op& op) {
 }
 
 int swin_exec(const ModelDef& def, const Op& op, ExecCtx& cx) {
-    mi355_model* m = cx.m;
-    SlotState* S = m->slots;
     switch (op.kind) {
         case OP_PATCH_EMBED: {
             MI355_REQUIRE(cx.H == 224 && cx.W == 224, "swin needs 224x224 input");
