@@ -228,3 +228,30 @@ def test_score_booster_matches_reference_formulas():
     with pytest.raises(M.MI355Error):
         M.cos_sim_score_booster(t, eps, alpha, "sideways")
     assert M.cos_sim_score_with_threshold(t[:0], eps, alpha, thr).shape == (0,)
+
+
+def test_query_blocking_over_a_3m_row_gallery():
+    """Q larger than the score-slab block (the slab S[qb][G] is capped at ~1 GiB, rank.hip query_block): 600 queries
+    against 3M rows are processed as three blocks of 256; the result must not depend on the blocking (same tile shape
+    for every block: compared against explicit 256-query calls) and match the oracle on probe rows."""
+    Qn, Gn, d, k = 600, 3_000_000, 64, 5
+    Q = M.synth_fill(Qn * d, 41, synth.NORMAL, DEV).view(Qn, d)
+    G = M.l2_normalize_rows(M.synth_fill(Gn * d, 42, synth.NORMAL, DEV).view(Gn, d))
+    v, i = M.cosine_topk(Q, G, k, gallery_is_normalized=True)
+    for lo in range(0, Qn, 256):
+        v2, i2 = M.cosine_topk(Q[lo:lo + 256], G, k, gallery_is_normalized=True)
+        if v2.shape[0] > 128:            # same GEMM tile class as the blocked call (Q > 64 -> 128-query tiles)
+            assert torch.equal(i[lo:lo + 256], i2) and torch.equal(v[lo:lo + 256], v2)
+        else:
+            assert torch.equal(i[lo:lo + 256], i2)
+            torch.testing.assert_close(v[lo:lo + 256], v2, atol=SCORE_TOL, rtol=0)
+    probes = [0, 255, 256, 511, 512, 599]
+    qn = Q[probes].cpu().numpy().astype(np.float64)
+    qn /= np.linalg.norm(qn, axis=1, keepdims=True)
+    g = G.cpu().numpy()
+    for r, p in enumerate(probes):
+        s = g @ qn[r].astype(np.float32)
+        order = np.lexsort((np.arange(Gn), -s))[:k + 1]
+        if np.min(s[order][:-1] - s[order][1:]) > 1e-5:
+            assert i[p].cpu().tolist() == order[:k].tolist()
+        np.testing.assert_allclose(v[p].cpu().numpy(), s[order[:k]], atol=SCORE_TOL)
