@@ -100,6 +100,22 @@ def test_deterministic_and_batch_invariant(setup):
     assert torch.equal(a, d)
 
 
+def test_full_batch_properties_b256(setup):
+    """BASELINE configs[1] size (bs = 256), through size-independent properties: run-to-run determinism, permutation
+    equivariance (bit-exact: no result depends on the image's position or neighbours), and agreement with the same
+    images embedded in a batch of 4 (different kernels are selected at small M, so only to rounding noise)."""
+    _, model = setup
+    B = 256
+    x = M.synth_fill(B * 3 * 224 * 224, 77, synth.UNIFORM, DEV).view(B, 3, 224, 224)
+    a = model(x)
+    assert a.shape[0] == B and torch.isfinite(a).all()
+    assert torch.equal(a, model(x))
+    perm = torch.from_numpy(np.random.RandomState(3).permutation(B)).to(DEV)
+    assert torch.equal(model(x[perm].contiguous()), a[perm])
+    small = model(x[:4].contiguous())
+    assert rel(small.cpu(), a[:4].cpu()) < 5e-3
+
+
 def test_num_classes_zero_and_head_swaps(setup):
     sd, _ = setup
     x = torch.from_numpy(images(7, 2)).to(DEV)

@@ -82,3 +82,26 @@ def test_rexnet_head_identity_and_determinism():
     e2 = model(x)
     model.set_option("fuse", 1)
     assert rel(e2, e) < 1e-2                            # fused and unfused executors agree to rounding
+
+
+def test_rexnet200_full_batch_properties_b256():
+    """BASELINE configs[2] size (rexnet_200, bs = 256): determinism, bit-exact permutation equivariance, agreement
+    with the same images in a batch of 4, and the cosine path on those embeddings (rank of the batch against itself:
+    every image's nearest neighbour is itself with score 1)."""
+    model = M.create_model("rexnet_200", num_classes=0, seed=4).to(DEV).eval()
+    B = 256
+    x = M.synth_fill(B * 3 * 224 * 224, 78, synth.UNIFORM, DEV).view(B, 3, 224, 224)
+    a = model(x)
+    assert a.shape == (B, 2560) and torch.isfinite(a).all()
+    assert torch.equal(a, model(x))
+    perm = torch.from_numpy(np.random.RandomState(5).permutation(B)).to(DEV)
+    assert torch.equal(model(x[perm].contiguous()), a[perm])
+    assert rel(model(x[:4].contiguous()).cpu(), a[:4].cpu()) < 5e-3
+    v, i = M.cosine_topk(a, a, 1)
+    np.testing.assert_allclose(v.cpu().numpy(), 1.0, atol=1e-5)
+    # uniform-noise images through a random-init net give near-identical embeddings: an index may only differ from the
+    # diagonal where another image's score is within the score tolerance of 1
+    s = M.cosine_scores(a, a)
+    off = (i[:, 0] != torch.arange(B, device=DEV)).nonzero().flatten()
+    for r in off.tolist():
+        assert float(s[r, int(i[r, 0])]) > 1.0 - 1e-5

@@ -69,3 +69,19 @@ def test_swin_state_dict_buffers_match_timm_definition():
     for k in msd:
         if k.endswith("relative_position_index") or k.endswith("attn_mask"):
             assert torch.equal(msd[k].float(), sd[k].float()), k
+
+
+def test_swin_full_batch_properties_b128():
+    """BASELINE configs[3] size (swin_base, bs = 128): determinism and bit-exact permutation equivariance of the
+    MFMA window-attention path, agreement with the same images in a batch of 2."""
+    import numpy as np
+    from imageretrievalresearch_amd import synth
+    model = M.create_model("swin_base_patch4_window7_224", num_classes=0, seed=6).to(DEV).eval()
+    B = 128
+    x = M.synth_fill(B * 3 * 224 * 224, 79, synth.UNIFORM, DEV).view(B, 3, 224, 224)
+    a = model(x)
+    assert a.shape == (B, 1024) and torch.isfinite(a).all()
+    assert torch.equal(a, model(x))
+    perm = torch.from_numpy(np.random.RandomState(7).permutation(B)).to(DEV)
+    assert torch.equal(model(x[perm].contiguous()), a[perm])
+    assert rel(model(x[:2].contiguous()).cpu(), a[:2].cpu()) < 5e-3
