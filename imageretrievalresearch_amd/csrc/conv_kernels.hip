@@ -185,7 +185,10 @@ _Pragma("unroll")
                 for (int j = 0; j < 8; ++j) psum[j] += acc[p][j];
                 // streaming store: the output is not re-read by this kernel, keep the L2 for the input rows that the
                 // neighbouring output rows are about to re-read
-                __builtin_nontemporal_store(pack8(acc[p]), reinterpret_cast<u32x4*>(o + (size_t)p * C));
+                // (narrow layers: a pixel's channels are < 128 bytes, so a store instruction writes partial lines; streamed
+                //  past the L2 they cost 1.6-2.1x their bytes at HBM (PMC WRITE_SIZE) - let the L2 merge them instead)
+                if (C >= 64) __builtin_nontemporal_store(pack8(acc[p]), reinterpret_cast<u32x4*>(o + (size_t)p * C));
+                else *reinterpret_cast<u32x4*>(o + (size_t)p * C) = pack8(acc[p]);
             }
         }
     }
