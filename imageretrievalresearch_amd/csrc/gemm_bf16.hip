@@ -559,9 +559,15 @@ __global__ __launch_bounds__(256) void k_gemm_stream(const GemmArgs g) {
         if (row < Npad && c * 8 < g.ldw) v = *reinterpret_cast<const u32x4*>(g.W + (size_t)row * g.ldw + c * 8);
         *reinterpret_cast<u32x4*>(&wsm[row * WLD + c * 8]) = v;
     }
+    {
+        float* sb = reinterpret_cast<float*>(wsm + NT * 16 * WLD + 4 * 16 * CLD);
+        for (int n = tid; n < NT * 16; n += 256) sb[n] = n < Npad ? g.bias[n] : 0.f;
+    }
     __syncthreads();
 
     bf16_t* cst = wsm + NT * 16 * WLD + wave * 16 * CLD;
+    // bias lives in LDS (after the four output strips), not in NT*4 registers per lane: the registers buy occupancy
+    const float* sbias = reinterpret_cast<const float*>(wsm + NT * 16 * WLD + 4 * 16 * CLD);
     const int fr = lane & 15, fq = lane >> 4;
     const int nslabs = (g.M + 15) >> 4;
     const int stride = gridDim.x * 4;
@@ -586,12 +592,6 @@ __global__ __launch_bounds__(256) void k_gemm_stream(const GemmArgs g) {
 #pragma unroll
     for (int p = 0; p < PF; ++p) load_slab(slab + p * stride, ring[p]);
 
-    f32x4 bias[NT];
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni) {
-        const int n = ni * 16 + fq * 4;
-        bias[ni] = n < Npad ? *reinterpret_cast<const f32x4*>(g.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
 
     while (slab < nslabs) {
 #pragma unroll
@@ -614,8 +614,9 @@ __global__ __launch_bounds__(256) void k_gemm_stream(const GemmArgs g) {
                 MI355_ACT_DISPATCH(g.act, {
 _Pragma("unroll")
                     for (int ni = 0; ni < NT; ++ni) {
-                        acc[ni].x = act_c<ACT>(acc[ni].x + bias[ni].x); acc[ni].y = act_c<ACT>(acc[ni].y + bias[ni].y);
-                        acc[ni].z = act_c<ACT>(acc[ni].z + bias[ni].z); acc[ni].w = act_c<ACT>(acc[ni].w + bias[ni].w);
+                        const f32x4 bb = *reinterpret_cast<const f32x4*>(&sbias[ni * 16 + fq * 4]);
+                        acc[ni].x = act_c<ACT>(acc[ni].x + bb.x); acc[ni].y = act_c<ACT>(acc[ni].y + bb.y);
+                        acc[ni].z = act_c<ACT>(acc[ni].z + bb.z); acc[ni].w = act_c<ACT>(acc[ni].w + bb.w);
                     }
                 })
                 // residual in registers (8-byte loads), then the slab goes through this wave's private LDS strip so
@@ -660,7 +661,7 @@ _Pragma("unroll")
 
 template <int NT, int KST>
 static int launch_stream_cfg(const GemmArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)NT * 16 * (KST * 32 + 8) * 2 + (size_t)4 * 16 * (NT * 16 + 8) * 2;
+    const size_t lds = (size_t)NT * 16 * (KST * 32 + 8) * 2 + (size_t)4 * 16 * (NT * 16 + 8) * 2 + (size_t)NT * 16 * 4;
     static bool attr_done = false;
     if (!attr_done) {
         MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_stream<NT, KST>,
@@ -676,14 +677,16 @@ static int launch_stream_cfg(const GemmArgs& a, hipStream_t st) {
 }
 
 // returns -1 when the shape is not covered (caller falls back to the tiled kernel).
-// Measured per layer (profiles/r01_effnet_per_op.txt vs tools/gemm_sweep.py): streaming wins where the output row is
-// wide and K is one k-step (24->144 @112x112: 0.375 -> 0.284 ms); the tiled kernel wins on 32->192 (0.131 vs 0.145),
-// 48->288 (0.056 vs 0.097) and on the gated projections, so only the first shape class is routed here.
+// Measured per layer (profiles/r01_effnet_per_op.txt, tools/gemm_sweep.py): streaming wins where the output row is wide and
+// K is ONE k-step: 24->144 @112x112 0.375 -> 0.284 ms, 32->192 @56x56 0.129 -> 0.107 ms (once the bias moved from 48
+// registers per lane to LDS; RexNet's 32->192 @112x112: 0.52 -> 0.40 ms).  The tiled kernel wins on 48->288 (two k-steps:
+// 0.052 vs 0.078 ms) and on every gated projection (re-measured after the epilogue fixes: 0.10 vs 0.12 ms on 192->32).
 static int try_launch_stream(const GemmArgs& a, hipStream_t st) {
     if (a.out_f32 || a.M < 4096 || a.N % 8 || a.ldo % 8 || a.gate || a.a_relu6) return -1;
     const int kst = (a.K + 31) / 32;
     const int nt = (a.N + 15) / 16;
     if (kst == 1 && nt == 9) return launch_stream_cfg<9, 1>(a, st);
+    if (kst == 1 && nt == 12) return launch_stream_cfg<12, 1>(a, st);
     return -1;
 }
 
