@@ -51,7 +51,8 @@ struct mi355_model {
     size_t arena_bytes = 0;
     SlotState slots[SLOT_COUNT];
     int microbatch = 0;
-    bool fuse_band = false;     // band variant for the early stages: measured slower than the unfused pair (option "fuse_band")
+    int fuse_band = 2;          // band variant for the early stages: 0 never, 1 wherever it fits, 2 (default) only the shape
+                                // class where it was measured faster than the unfused pair: 3x3 stride-1 with bands of >= 8 rows
     bool fuse = true;           // fused expand+depthwise for whole-image tiles (option "fuse")
     int fuse_debug = 0;
     int pool_nblk = 0;          // squeeze partials per image produced by the last depthwise stage
