@@ -268,8 +268,11 @@ static bool can_fuse(const mi355_model* m, size_t i, int h, int w) {
     // Band variant, measured per layer on EfficientNet-B3a B=256 (fused vs expand + depthwise): 3x3 s1 C192 @56x56 307 vs
     // 339 us (wins); 3x3 s2 C144 @112x112 780 vs 619, 5x5 s2 C192 @56x56 465 vs 276, 5x5 s1 C288 @28x28 247 vs 172 (lose:
     // short bands recompute too much halo and leave most threads idle in the depthwise phase).
+    // RexNet-200: 3x3 s1 C324 @56x56 (7-row bands) 582 vs 661 us and 3x3 s2 C192 @112x112 714 vs 771 us (win: its 32->192
+    // expand alone costs 0.5 ms).
     const int rows = m->fuse_band ? fused_band_rows(h, w, g.cin, g.cout, d.k, d.stride) : 0;
-    return rows > 0 && (m->fuse_band == 1 || (d.k == 3 && d.stride == 1 && rows >= 8));
+    const bool measured_win = d.k == 3 && ((d.stride == 1 && rows >= 7) || (d.stride == 2 && w >= 112 && g.cout >= 192));
+    return rows > 0 && (m->fuse_band == 1 || measured_win);
 }
 
 static int exec_fused(ExecCtx& cx, const Op& g, const Op& d) {

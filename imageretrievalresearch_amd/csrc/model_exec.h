@@ -52,7 +52,7 @@ struct mi355_model {
     SlotState slots[SLOT_COUNT];
     int microbatch = 0;
     int fuse_band = 2;          // band variant for the early stages: 0 never, 1 wherever it fits, 2 (default) only the shape
-                                // class where it was measured faster than the unfused pair: 3x3 stride-1 with bands of >= 8 rows
+                                // classes where it was measured faster than the unfused pair (see can_fuse in model.hip)
     bool fuse = true;           // fused expand+depthwise for whole-image tiles (option "fuse")
     int fuse_debug = 0;
     int pool_nblk = 0;          // squeeze partials per image produced by the last depthwise stage
