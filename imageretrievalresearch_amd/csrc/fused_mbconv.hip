@@ -282,12 +282,16 @@ _Pragma("unroll")
 // sub-tiles with the slab's W fragments held in registers); phase 2 is the same depthwise as above.
 // The SE squeeze becomes one partial sum per (image, band): pool[b][band][mid].
 // =====================================================================================
-template <int KS, int S, int KST, int PX>
+template <int KS, int S, int KST, int PX, int MC>
 __global__ __launch_bounds__(FL_THREADS) void k_fused_band(const FusedArgs a) {
-    constexpr int MC = 64, NT = 4;
+    // MC = channels per slab (48 / 64 / 96, picked to divide the expanded width: a 64-wide slab wasted a third of both
+    // phases on mid = 144); NACT = the largest multiple of the slab's channel groups <= 512, so that a thread keeps ONE
+    // channel group over all its items (its squeeze partial sums stay per channel)
+    constexpr int NT = MC / 16;
     constexpr int PAD = KS / 2;
     constexpr int IW = (PX - 1) * S + KS;
     constexpr int CGC = MC / 8;
+    constexpr int NACT = (FL_THREADS / CGC) * CGC;
     constexpr int Kp = 32 * KST, XLD = Kp + 8, ELD = MC + 8;
     extern __shared__ __attribute__((aligned(16))) bf16_t fsm[];
     const int band = blockIdx.x, b = blockIdx.y;
@@ -305,19 +309,43 @@ __global__ __launch_bounds__(FL_THREADS) void k_fused_band(const FusedArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {
+        // X band -> LDS with four 16-byte loads in flight per thread; of the E image only the pad columns (and the slack
+        // behind the last row) must be zero - phase 1 rewrites every interior pixel for every slab
         constexpr int kc = Kp >> 3;
+        constexpr int U = 4;
         const bf16_t* xb = a.X + (size_t)b * a.H * a.W * a.Cin;
-        for (int id = tid; id < MT * 16 * kc; id += FL_THREADS) {
-            const int row = id / kc, c = id - row * kc;
-            const int r = row / a.W, x = row - r * a.W;
-            const int iy = iy0 + r;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (row < P && iy >= 0 && iy < a.H && c * 8 < a.Cin)
-                v = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * a.W + x) * a.Cin + c * 8);
-            *reinterpret_cast<u32x4*>(&Xs[row * XLD + c * 8]) = v;
+        const int total = MT * 16 * kc;
+        for (int id0 = tid; id0 < total; id0 += FL_THREADS * U) {
+            u32x4 v[U];
+            int dst[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int id = id0 + u * FL_THREADS;
+                const int row = id / kc, c = id - row * kc;
+                const int r = row / a.W, x = row - r * a.W;
+                const int iy = iy0 + r;
+                v[u] = (u32x4){0u, 0u, 0u, 0u};
+                dst[u] = id < total ? row * XLD + c * 8 : -1;
+                if (id < total && row < P && iy >= 0 && iy < a.H && c * 8 < a.Cin)
+                    v[u] = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * a.W + x) * a.Cin + c * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (dst[u] >= 0) *reinterpret_cast<u32x4*>(&Xs[dst[u]]) = v[u];
         }
-        for (int id = tid; id < EP * (ELD / 8); id += FL_THREADS)
-            *reinterpret_cast<u32x4*>(&Es[(size_t)id * 8]) = (u32x4){0u, 0u, 0u, 0u};
+        constexpr int EV = ELD / 8;                      // 16-byte vectors per E pixel
+        const int npad = IH * 2 * PAD + IW;              // pad pixels per row (left + right) and the tail slack
+        for (int id = tid; id < npad * EV; id += FL_THREADS) {
+            const int q = id / EV, vv = id - q * EV;
+            int px;
+            if (q < IH * 2 * PAD) {
+                const int r = q / (2 * PAD), j = q - r * 2 * PAD;
+                px = r * EW + (j < PAD ? j : a.W + j);    // j >= PAD: right pad column PAD + W + (j - PAD)
+            } else {
+                px = IH * EW + (q - IH * 2 * PAD);
+            }
+            *reinterpret_cast<u32x4*>(&Es[(size_t)px * ELD + vv * 8]) = (u32x4){0u, 0u, 0u, 0u};
+        }
     }
     __syncthreads();
 
@@ -330,7 +358,7 @@ __global__ __launch_bounds__(FL_THREADS) void k_fused_band(const FusedArgs a) {
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int cbase = chunk * MC;
         // ---- phase 1: waves split the pixel sub-tiles; the slab's W fragments + bias live in registers
-        {
+        if (!(a.debug_skip & 1)) {
             bf16x8 wf[NT][KST];
             f32x4 bb[NT];
 #pragma unroll
@@ -387,8 +415,9 @@ _Pragma("unroll")
         for (int j = 0; j < 8; ++j) psum[j] = 0.f;
         const int my_cg = tid % CGC;
         const int c0 = cbase + my_cg * 8;
-        const bool cok = c0 < a.mid;
-        for (int item = tid; item < nitems; item += FL_THREADS) {
+        const bool cok = c0 < a.mid && tid < NACT;
+        if (!(a.debug_skip & 2))
+        for (int item = tid; item < nitems && tid < NACT; item += NACT) {
             const int rest = item / CGC;
             const int sx = rest % strips, oy = oy0 + rest / strips;
             const int ox0 = sx * PX;
@@ -449,18 +478,20 @@ _Pragma("unroll")
 #pragma unroll
             for (int j = 0; j < 8; ++j) red[tid * 8 + j] = psum[j];
             __syncthreads();
-            // two fixed-order stages: 8 threads per channel group add 8 entries each, then one thread adds the 8 parts
+            // two fixed-order stages: 8 threads per channel group add a contiguous share of that group's NACT / CGC
+            // entries, then one thread per group adds the 8 parts
+            constexpr int PER = NACT / CGC, SHARE = (PER + 7) / 8;
             float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (tid < 64) {
-                const int cg = tid & 7, part = tid >> 3;
-                for (int j2 = 0; j2 < 8; ++j2) {
-                    const int u = cg + CGC * (part * 8 + j2);
+            if (tid < CGC * 8) {
+                const int cg = tid % CGC, part = tid / CGC;
+                for (int i = part * SHARE; i < (part + 1) * SHARE && i < PER; ++i) {
+                    const int u = cg + CGC * i;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) s[j] += red[u * 8 + j];
                 }
             }
             __syncthreads();
-            if (tid < 64) {
+            if (tid < CGC * 8) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) red[tid * 8 + j] = s[j];
             }
@@ -469,7 +500,7 @@ _Pragma("unroll")
                 float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 for (int part = 0; part < 8; ++part)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) t[j] += red[(part * 8 + tid) * 8 + j];
+                    for (int j = 0; j < 8; ++j) t[j] += red[(part * CGC + tid) * 8 + j];
                 float* pp = a.pool + ((size_t)b * gridDim.x + band) * a.mid + cbase + tid * 8;
                 *reinterpret_cast<f32x4*>(pp) = (f32x4){t[0], t[1], t[2], t[3]};
                 *reinterpret_cast<f32x4*>(pp + 4) = (f32x4){t[4], t[5], t[6], t[7]};
@@ -479,11 +510,13 @@ _Pragma("unroll")
     }
 }
 
-static size_t band_lds_bytes(int W, int Kp, int k, int stride, int TH, int px) {
+static int band_slab(int mid) { return mid % 64 == 0 ? 64 : (mid % 48 == 0 ? 48 : (mid % 96 == 0 ? 96 : 64)); }
+
+static size_t band_lds_bytes(int W, int Kp, int k, int stride, int TH, int px, int mc) {
     const int pad = k / 2, IH = (TH - 1) * stride + k;
     const int P = IH * W, MT = (P + 15) / 16, iw = (px - 1) * stride + k;
     const int EP = IH * (W + 2 * pad) + iw;
-    return (size_t)MT * 16 * (Kp + 8) * 2 + (size_t)((EP + 7) & ~7) * 72 * 2 + FL_THREADS * 8 * 4;
+    return (size_t)MT * 16 * (Kp + 8) * 2 + (size_t)((EP + 7) & ~7) * (mc + 8) * 2 + FL_THREADS * 8 * 4;
 }
 
 // Largest band height (output rows) whose LDS image fits; 0 = unsupported.
@@ -495,29 +528,37 @@ int fused_band_rows(int H, int W, int Cin, int mid, int k, int stride) {
     const int px = Wo % 7 == 0 ? 7 : 4;
     int best = 0;
     for (int th = 1; th <= Ho && th <= 16; ++th)
-        if (band_lds_bytes(W, Kp, k, stride, th, px) <= 158 * 1024) best = th;
+        if (band_lds_bytes(W, Kp, k, stride, th, px, band_slab(mid)) <= 158 * 1024) best = th;
     return best;
 }
 
-template <int KS, int S, int KST, int PX>
+template <int KS, int S, int KST, int PX, int MC>
 static int launch_fb(const FusedArgs& a, int B, hipStream_t st) {
-    const size_t lds = band_lds_bytes(a.W, a.Kp, KS, S, a.TH, PX);
+    const size_t lds = band_lds_bytes(a.W, a.Kp, KS, S, a.TH, PX, MC);
     static bool attr_done = false;
     if (!attr_done) {
-        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_fused_band<KS, S, KST, PX>,
+        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_fused_band<KS, S, KST, PX, MC>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_fused_band<KS, S, KST, PX>), dim3(cdiv(a.Ho, a.TH), B), dim3(FL_THREADS), lds, st, a);
+    hipLaunchKernelGGL((k_fused_band<KS, S, KST, PX, MC>), dim3(cdiv(a.Ho, a.TH), B), dim3(FL_THREADS), lds, st, a);
     MI355_LAUNCH_CHECK();
     return OK;
+}
+
+template <int KS, int S, int KST, int PX>
+static int launch_fb_mc(const FusedArgs& a, int B, hipStream_t st) {
+    const int mc = band_slab(a.mid);
+    if (mc == 48) return launch_fb<KS, S, KST, PX, 48>(a, B, st);
+    if (mc == 96) return launch_fb<KS, S, KST, PX, 96>(a, B, st);
+    return launch_fb<KS, S, KST, PX, 64>(a, B, st);
 }
 
 template <int KS, int S>
 static int launch_fb_ks(const FusedArgs& a, int B, hipStream_t st) {
     const bool px7 = (a.Wo % 7 == 0);
-    if (a.Kp == 32) return px7 ? launch_fb<KS, S, 1, 7>(a, B, st) : launch_fb<KS, S, 1, 4>(a, B, st);
-    return px7 ? launch_fb<KS, S, 2, 7>(a, B, st) : launch_fb<KS, S, 2, 4>(a, B, st);
+    if (a.Kp == 32) return px7 ? launch_fb_mc<KS, S, 1, 7>(a, B, st) : launch_fb_mc<KS, S, 1, 4>(a, B, st);
+    return px7 ? launch_fb_mc<KS, S, 2, 7>(a, B, st) : launch_fb_mc<KS, S, 2, 4>(a, B, st);
 }
 
 int launch_fused_band(const FusedArgs& a, int B, int k, int stride, hipStream_t st) {
