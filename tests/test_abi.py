@@ -33,3 +33,31 @@ def test_argument_errors_do_not_need_a_gpu():
     assert b"null" in L.mi355_last_error()
     assert L.mi355_rank_workspace_bytes(256, 100000, 1536, 3) > 256 * 100000 * 4
     assert L.mi355_rank_workspace_bytes(0, 10, 8, 1) == 0
+
+
+def test_product_package_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under imageretrievalresearch_amd/ may import it (a product path that
+    routes through the oracle would void every parity claim); bench.py may, inside its cpu_baseline leg only."""
+    import ast
+    import os
+    from helpers import ROOT
+    pkg = os.path.join(ROOT, "imageretrievalresearch_amd")
+    for fn in sorted(os.listdir(pkg)):
+        if not fn.endswith(".py"):
+            continue
+        tree = ast.parse(open(os.path.join(pkg, fn)).read())
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            assert not any(n == "oracle" or n.startswith("oracle.") for n in names), (fn, names)
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    for node in tree.body:                               # module level: no oracle import
+        if isinstance(node, (ast.Import, ast.ImportFrom)):
+            names = [a.name for a in node.names] if isinstance(node, ast.Import) else [node.module or ""]
+            assert not any(n.startswith("oracle") for n in names), names
+    fn_imports = {f.name: [n for n in ast.walk(f) if isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle")]
+                  for f in tree.body if isinstance(f, ast.FunctionDef)}
+    assert [k for k, v in fn_imports.items() if v] == ["cpu_baseline"], fn_imports
