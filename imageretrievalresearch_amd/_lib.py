@@ -56,6 +56,7 @@ PROTOTYPES = {
     "mi355_model_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
     "mi355_model_profile_ops": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
                                           C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
+    "mi355_model_block_stamps": (C.c_int, [vp, C.POINTER(C.c_double), C.c_int]),
     "mi355_gemm_bf16": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mi355_square_pad_normalize": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp]),
     "mi355_conv_input_silu": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),

@@ -55,6 +55,7 @@ struct Op {
     float ln_eps = 1e-5f;
     // packed-weight offsets (bytes into the device blob), filled by pack()
     size_t w_off = 0, b_off = 0, w2_off = 0, b2_off = 0, aux_off = 0;
+    size_t w3_off = 0, w4_off = 0;  // SE: bf16 copies of the two FC matrices (whole-block kernel, mbconv_block.hip)
     // source tensors (timm keys) for packing
     std::string w_name, bn_name, bias_name, w2_name, bias2_name, bn2_name, aux_name;
     float bn_eps = 1e-5f;

@@ -95,12 +95,24 @@ static int pack_se(Packer& pk, Op& op) {
     float* W2 = (float*)(pk.blob.data() + op.w2_off);
     float* B2 = (float*)(pk.blob.data() + op.b2_off);
     for (int j = 0; j < rd; ++j) {
-        for (int c = 0; c < C; ++c) W1[(size_t)j * Cp + c] = w1->data[(size_t)j * C + c] * scale[j];
+        for (int c = 0; c < C; ++c) W1[(size_t)j * Cp + c] = bf_round_host(w1->data[(size_t)j * C + c] * scale[j]);   // bf16 values (see below)
         B1[j] = b1->data[j] * scale[j] + shift[j];
     }
     for (int c = 0; c < C; ++c) {
-        for (int j = 0; j < rd; ++j) W2[(size_t)j * Cp + c] = w2->data[(size_t)c * rd + j];   // transposed [rd][Cp]
+        for (int j = 0; j < rd; ++j) W2[(size_t)j * Cp + c] = bf_round_host(w2->data[(size_t)c * rd + j]);   // transposed [rd][Cp]
         B2[c] = b2->data[c];
+    }
+    // bf16 copies for the whole-block kernel (every workgroup streams both matrices from L2: half the bytes).  The fp32
+    // copies above hold the same bf16-rounded values, so k_se and the block kernel compute the same gate.
+    op.w3_off = pk.alloc((size_t)rd * Cp * 2);
+    op.w4_off = pk.alloc((size_t)rd * Cp * 2);
+    {
+        // (alloc may have moved the blob: re-derive the fp32 views)
+        const float* W1f = (const float*)(pk.blob.data() + op.w_off);
+        const float* W2f = (const float*)(pk.blob.data() + op.w2_off);
+        uint16_t* W1b = (uint16_t*)(pk.blob.data() + op.w3_off);
+        uint16_t* W2b = (uint16_t*)(pk.blob.data() + op.w4_off);
+        for (size_t i = 0; i < (size_t)rd * Cp; ++i) { W1b[i] = f2bf_host(W1f[i]); W2b[i] = f2bf_host(W2f[i]); }
     }
     return OK;
 }
@@ -275,6 +287,58 @@ static bool can_fuse(const mi355_model* m, size_t i, int h, int w) {
     return rows > 0 && (m->fuse_band == 1 || measured_win);
 }
 
+// expand GEMM -> depthwise -> SE -> gated projection on a whole-image tile: one kernel (mbconv_block.hip)
+static bool can_fuse_block(const mi355_model* m, size_t i, int h, int w, int nb) {
+    if (!m->fuse_block || nb < m->fuse_block_min_batch || i + 3 >= m->def.ops.size()) return false;
+    const Op& g = m->def.ops[i];
+    const Op& d = m->def.ops[i + 1];
+    const Op& s = m->def.ops[i + 2];
+    const Op& p = m->def.ops[i + 3];
+    if (g.kind != OP_GEMM || d.kind != OP_DW || s.kind != OP_SE || p.kind != OP_GEMM) return false;
+    if (g.out != SLOT_E || d.in != SLOT_E || d.out != SLOT_D || p.in != SLOT_D || !p.use_gate || !d.pool) return false;
+    if (g.use_gate || g.res != SLOT_NONE || g.a_relu6 || !g.tap.empty() || !d.tap.empty()) return false;
+    if (p.a_relu6 || p.act != ACT_NONE || (p.res != SLOT_NONE && (p.res != g.in || p.res_channels != 0))) return false;
+    if (g.cin != g.cin_real || g.cout != g.cout_real || p.cout != p.cout_real) return false;   // no padded channels
+    return mbconv_block_supported(h, w, g.cin, g.cout, p.cout, d.k, d.stride, s.rd);
+}
+
+static int exec_block(ExecCtx& cx, size_t oi) {
+    mi355_model* m = cx.m;
+    SlotState* S = m->slots;
+    const Op& g = m->def.ops[oi];
+    const Op& d = m->def.ops[oi + 1];
+    const Op& s = m->def.ops[oi + 2];
+    const Op& p = m->def.ops[oi + 3];
+    BlockArgs a{};
+    a.X = (const bf16_t*)cx.slot_ptr(g.in);
+    a.We = (const bf16_t*)cx.w(g.w_off); a.be = (const float*)cx.w(g.b_off);
+    a.Wd = (const bf16_t*)cx.w(d.w_off); a.bd = (const float*)cx.w(d.b_off);
+    a.W1 = (const bf16_t*)cx.w(s.w3_off); a.b1 = (const float*)cx.w(s.b_off);
+    a.W2 = (const bf16_t*)cx.w(s.w4_off); a.b2 = (const float*)cx.w(s.b2_off);
+    a.Wp = (const bf16_t*)cx.w(p.w_off); a.bp = (const float*)cx.w(p.b_off);
+    a.D = (bf16_t*)cx.slot_ptr(d.out);
+    a.Y = (bf16_t*)cx.slot_ptr(p.out);
+    a.H = S[g.in].h; a.W = S[g.in].w; a.Cin = g.cin; a.Kp = (g.cin + 31) & ~31; a.mid = g.cout;
+    a.Ho = S[d.out].h; a.Wo = S[d.out].w; a.Cout = p.cout; a.Kp2 = (p.cin + 31) & ~31; a.rd = s.rd;
+    a.has_res = p.res != SLOT_NONE;
+    a.act_e = g.act; a.act_d = d.act; a.se_act = s.se_act;
+    a.inv_hw = 1.0f / (float)(a.Ho * a.Wo);
+    a.norot = m->block_norot;
+    a.stamps = nullptr;
+    if (m->block_stamps) {
+        const size_t need = m->def.ops.size() * (size_t)cx.B * 16 * sizeof(long long);
+        if (m->stamp_bytes < need) {
+            if (m->stamp_buf) MI355_CHECK_HIP(hipFree(m->stamp_buf));
+            MI355_CHECK_HIP(hipMalloc((void**)&m->stamp_buf, need));
+            MI355_CHECK_HIP(hipMemsetAsync(m->stamp_buf, 0, need, cx.st));
+            m->stamp_bytes = need;
+        }
+        m->stamp_B = cx.B;
+        a.stamps = m->stamp_buf + (oi * (size_t)cx.B + cx.b0) * 16;
+    }
+    return launch_mbconv_block(a, cx.nb, d.k, d.stride, cx.st);
+}
+
 static int exec_fused(ExecCtx& cx, const Op& g, const Op& d) {
     mi355_model* m = cx.m;
     SlotState* S = m->slots;
@@ -304,12 +368,18 @@ static int run_backbone(ExecCtx& cx) {
     for (size_t oi = 0; oi < m->def.ops.size(); ++oi) {
         const Op& op = m->def.ops[oi];
         const int op_index = (int)oi;
-        const bool fused = can_fuse(m, oi, S[op.in == SLOT_NONE ? 0 : op.in].h, S[op.in == SLOT_NONE ? 0 : op.in].w);
+        const int in_h = S[op.in == SLOT_NONE ? 0 : op.in].h, in_w = S[op.in == SLOT_NONE ? 0 : op.in].w;
+        const bool block = op.in != SLOT_NONE && can_fuse_block(m, oi, in_h, in_w, cx.nb);
+        const bool fused = block || can_fuse(m, oi, in_h, in_w);
         if (fused) {   // dims of the (virtual) expand output and of the depthwise output
             const Op& d = m->def.ops[oi + 1];
             S[op.out].h = S[op.in].h; S[op.out].w = S[op.in].w; S[op.out].c = op.cout;
             S[d.out].h = conv_out(S[op.in].h, d.k, d.stride); S[d.out].w = conv_out(S[op.in].w, d.k, d.stride);
             S[d.out].c = d.cout;
+            if (block) {
+                const Op& pj = m->def.ops[oi + 3];
+                S[pj.out].h = S[d.out].h; S[pj.out].w = S[d.out].w; S[pj.out].c = pj.cout;
+            }
         } else
         switch (op.kind) {
             case OP_STEM: S[op.out].h = conv_out(cx.H, 3, 2); S[op.out].w = conv_out(cx.W, 3, 2); S[op.out].c = op.cout; break;
@@ -328,7 +398,9 @@ static int run_backbone(ExecCtx& cx) {
             MI355_CHECK_HIP(hipEventCreate(&e1));
             MI355_CHECK_HIP(hipEventRecord(e0, cx.st));
         }
-        if (fused) {
+        if (block) {
+            if (int e = exec_block(cx, oi)) return e;
+        } else if (fused) {
             if (int e = exec_fused(cx, op, m->def.ops[oi + 1])) return e;
         } else if (int e = exec_op(cx, op)) return e;
         if (m->profile) {
@@ -336,6 +408,13 @@ static int run_backbone(ExecCtx& cx) {
             m->prof_events.push_back({op_index, {e0, e1}});
             if (m->prof_fused.size() < m->def.ops.size()) m->prof_fused.resize(m->def.ops.size(), 0);
             m->prof_fused[op_index] = fused ? 1 : 0;
+        }
+        if (block) {
+            const Op& pj = m->def.ops[oi + 3];
+            if (m->taps && !pj.tap.empty())
+                if (int e = record_tap(cx, pj)) return e;
+            oi += 3;       // depthwise, SE and projection ran inside the block kernel
+            continue;
         }
         if (m->taps && !op.tap.empty())
             if (int e = record_tap(cx, op)) return e;
@@ -440,6 +519,7 @@ void mi355_model_destroy(mi355_model_t m) {
     if (!m) return;
     if (m->dev_blob) (void)hipFree(m->dev_blob);
     if (m->arena) (void)hipFree(m->arena);
+    if (m->stamp_buf) (void)hipFree(m->stamp_buf);
     for (auto& kv : m->tapbufs)
         if (kv.second.ptr) (void)hipFree(kv.second.ptr);
     delete m;
@@ -535,6 +615,10 @@ int mi355_model_set_option(mi355_model_t m, const char* key, int64_t value) {
     else if (k == "fuse") m->fuse = value != 0;
     else if (k == "fuse_band") m->fuse_band = (int)value;
     else if (k == "fuse_debug") m->fuse_debug = (int)value;
+    else if (k == "fuse_block") m->fuse_block = (int)value;
+    else if (k == "fuse_block_min_batch") m->fuse_block_min_batch = (int)value;
+    else if (k == "block_stamps") m->block_stamps = value != 0;
+    else if (k == "block_norot") m->block_norot = (int)value;
     else if (k == "profile") {
         m->profile = value != 0;
         for (int i = 0; i < PK_COUNT; ++i) { m->prof_ms[i] = 0; m->prof_launches[i] = 0; }
@@ -632,6 +716,7 @@ int mi355_model_traffic_kinds(mi355_model_t m, int B, int H, int W, double* byte
     for (size_t oi = 0; oi < m->def.ops.size(); ++oi) {
         const Op& op = m->def.ops[oi];
         int kd = prof_kind(op);
+        if (fused_left == 0 && op.in != SLOT_NONE && can_fuse_block(m, oi, S[op.in].h, S[op.in].w, B)) fused_left = 4;
         if (fused_left == 0 && op.in != SLOT_NONE && can_fuse(m, oi, S[op.in].h, S[op.in].w)) fused_left = 2;
         if (fused_left > 0) { kd = PK_FUSED; --fused_left; }
         switch (op.kind) {
@@ -686,6 +771,24 @@ int mi355_model_traffic(mi355_model_t m, int B, int H, int W, double* act_bytes,
     if (macs) *macs = tm;
     if (weight_bytes) *weight_bytes = (double)m->blob.size();
     return OK;
+}
+
+// Diagnosis: per-phase cycle counts of the whole-block kernel (option "block_stamps"), averaged over the images of the
+// last forward.  out[op][16]: cycle buckets of wave 0 (the list is at the end of k_mbconv_block).
+// Synchronises the device.  Returns the number of ops (rows) or a negative error.
+int mi355_model_block_stamps(mi355_model_t m, double* out, int max_ops) {
+    MI355_REQUIRE(m && out, "block_stamps: null argument");
+    const int n = (int)m->def.ops.size();
+    MI355_REQUIRE(max_ops >= n, "block_stamps: need room for %d ops", n);
+    for (int i = 0; i < n * 16; ++i) out[i] = 0.0;
+    if (!m->stamp_buf || m->stamp_B <= 0) return n;
+    MI355_CHECK_HIP(hipDeviceSynchronize());
+    std::vector<long long> h((size_t)n * m->stamp_B * 16);
+    MI355_CHECK_HIP(hipMemcpy(h.data(), m->stamp_buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i)
+        for (int b = 0; b < m->stamp_B; ++b)
+            for (int j = 0; j < 16; ++j) out[i * 16 + j] += (double)h[((size_t)i * m->stamp_B + b) * 16 + j] / m->stamp_B;
+    return n;
 }
 
 int mi355_gemm_bf16(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int ldw, int act,

@@ -54,6 +54,11 @@ struct mi355_model {
     int fuse_band = 2;          // band variant for the early stages: 0 never, 1 wherever it fits, 2 (default) only the shape
                                 // classes where it was measured faster than the unfused pair (see can_fuse in model.hip)
     bool fuse = true;           // fused expand+depthwise for whole-image tiles (option "fuse")
+    int fuse_block = 1;         // whole MBConv block in one kernel for the 14x14 / 7x7 stages (option "fuse_block"; 0 = off)
+    int fuse_block_min_batch = 1;   // ... only for chunks of at least this many images
+    int block_norot = 0;        // diagnosis (option "block_norot"): see BlockArgs::norot
+    bool block_stamps = false;  // option "block_stamps": record per-phase cycle counts of the block kernel
+    long long* stamp_buf = nullptr; size_t stamp_bytes = 0; int stamp_B = 0;
     int fuse_debug = 0;
     int pool_nblk = 0;          // squeeze partials per image produced by the last depthwise stage
     bool taps = false;

@@ -43,6 +43,27 @@ int launch_fused_late(const FusedArgs& a, int B, int k, int stride, hipStream_t 
 int fused_band_rows(int H, int W, int Cin, int mid, int k, int stride);   // 0 = unsupported
 int launch_fused_band(const FusedArgs& a, int B, int k, int stride, hipStream_t st);
 
+// ---- whole MBConv block for the late stages (mbconv_block.hip): expand -> depthwise -> SE -> gated projection (+ residual)
+struct BlockArgs {
+    const bf16_t* X;                      // [B][H][W][Cin] block input (also the residual)
+    const bf16_t* We; const float* be;    // expand weights [midPad16][Kp] (GEMM packing) + folded-BN bias
+    const bf16_t* Wd; const float* bd;    // depthwise weights [k*k][mid] + bias [mid]
+    const bf16_t* W1; const float* b1;    // SE reduce [rd][mid] bf16 + bias [rd]
+    const bf16_t* W2; const float* b2;    // SE expand, transposed [rd][mid] bf16 + bias [mid]
+    const bf16_t* Wp; const float* bp;    // projection weights [CoutPad16][Kp2] + folded-BN bias
+    bf16_t* D;                            // scratch [B][Ho*Wo][mid]: depthwise output (round trip through L2)
+    bf16_t* Y;                            // [B][Ho][Wo][Cout] block output
+    long long* stamps;                    // optional [B][8] phase cycle counts (diagnosis), may be null
+    int H, W, Cin, Kp, mid, Ho, Wo, Cout, Kp2, rd;
+    int XLD;                              // LDS row stride of the X image (set by the launcher)
+    int norot;                            // diagnosis: bit0 slabs, bit1 SE FC1, bit2 SE FC2, bit3 projection columns NOT rotated by image
+    int has_res;
+    int act_e, act_d, se_act;
+    float inv_hw;
+};
+bool mbconv_block_supported(int H, int W, int Cin, int mid, int Cout, int k, int stride, int rd);
+int launch_mbconv_block(const BlockArgs& a, int B, int k, int stride, hipStream_t st);
+
 // ---- convolution-side kernels (conv_kernels.hip) -----------------------------------------------
 // Stem: x [B][3][H][W] fp32 NCHW -> out [B][Ho][Wo][Cout] bf16, 3x3 stride 2 pad 1, + bias + act.
 // w [3*3*3][Cout] fp32 laid out (ky, kx, ci) major, bias fp32 [Cout].

@@ -272,6 +272,16 @@ class MI355Model(nn.Module):
         kinds = ["stem", "gemm", "dw", "se", "other", "attn", "ln", "fused"]
         return [(lab.raw[i * 64:(i + 1) * 64].split(b"\0")[0].decode(), kinds[kd[i]], ms[i], by[i]) for i in range(cnt)]
 
+    def block_stamps(self):
+        """Per-op phase cycle counts of the whole-block kernel (after ``set_option('block_stamps', 1)`` and a forward):
+        list of (op_index, [16 cycle buckets]) for the ops that ran as a block (bucket list: end of k_mbconv_block)."""
+        n = 1024
+        out = (C.c_double * (n * 16))()
+        cnt = lib().mi355_model_block_stamps(self._handle, out, n)
+        if cnt < 0:
+            check(1)
+        return [(i, [out[i * 16 + j] for j in range(16)]) for i in range(cnt) if sum(out[i * 16:i * 16 + 16]) > 0]
+
     def enable_taps(self, on: bool = True):
         check(lib().mi355_model_enable_taps(self._handle, int(on)))
         return self

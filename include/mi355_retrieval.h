@@ -167,6 +167,8 @@ int mi355_model_traffic_kinds(mi355_model_t m, int B, int H, int W, double* byte
 
 /* Executor options: "microbatch" (images per pass through the layer plan; 0 = whole batch),
  * "fuse" (1 = run expand+depthwise pairs on whole-image tiles as one LDS-resident kernel; default 1),
+ * "fuse_block" (1 = run whole MBConv blocks of the 14x14 / 7x7 stages - expand, depthwise, SE, gated projection, residual -
+ *  as ONE kernel per block; default 1), "fuse_block_min_batch" (use it only for batches of at least this many images),
  * "profile" (1 = bracket every op with hipEvents on the launch stream; resets the accumulators). */
 int mi355_model_set_option(mi355_model_t m, const char* key, int64_t value);
 /* Accumulated per-kind kernel time (ms) and launch counts since "profile" was enabled; synchronises. */
@@ -177,6 +179,12 @@ int mi355_model_profile_read(mi355_model_t m, double* ms_by_kind, int64_t* launc
  * (callers size the arrays with max_ops >= that; 1024 is always enough).  Developer/bench tool. */
 int mi355_model_profile_ops(mi355_model_t m, int B, int H, int W, int max_ops, double* avg_ms, double* bytes,
                             int* kinds, char* labels, int label_stride);
+
+/* Diagnosis of the whole-MBConv-block kernel (option "block_stamps" = 1): per-phase shader-cycle counts of the LAST forward,
+ * averaged over its images.  out[op][16] in plan order (rows of ops that did not run as a block kernel stay 0); the 16
+ * buckets are listed at the end of k_mbconv_block (csrc/mbconv_block.hip).  Synchronises the device.  Returns the number
+ * of ops (size out with 16 * max_ops doubles, max_ops >= that; 1024 is always enough) or a negative error.  Developer tool. */
+int mi355_model_block_stamps(mi355_model_t m, double* out, int max_ops);
 
 /* Stand-alone 1x1-conv / linear kernel (the model executor's GEMM): out[M][N] bf16 = act(A[M][K] bf16 * W^T + bias).
  * W is bf16 [ceil16(N)][ldw] with ldw = K rounded up to 32, zero padded; bias fp32 [ceil16(N)]; K, N multiples of 8.

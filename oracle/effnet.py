@@ -86,10 +86,11 @@ def _conv_bn(x, sd, conv, bn, rb, stride=1, pad=0, groups=1, act=True):
 
 def _se(x, sd, p, rb):
     """SE on the fp32 (pre-rounding) activation: mean -> conv_reduce(+b) -> SiLU -> conv_expand(+b)
-    -> sigmoid.  Returns the gate; the HIP path keeps SE weights and the gate in fp32."""
+    -> sigmoid.  Returns the gate.  The HIP path stores the two FC matrices in bf16 (``rb`` in sim mode; every image's
+    workgroup streams them from L2) and keeps biases, accumulation and the gate in fp32."""
     s = x.mean((2, 3), keepdim=True)
-    r = F.silu(F.conv2d(s, sd[f"{p}.se.conv_reduce.weight"], sd[f"{p}.se.conv_reduce.bias"]))
-    return torch.sigmoid(F.conv2d(r, sd[f"{p}.se.conv_expand.weight"], sd[f"{p}.se.conv_expand.bias"]))
+    r = F.silu(F.conv2d(s, rb(sd[f"{p}.se.conv_reduce.weight"]), sd[f"{p}.se.conv_reduce.bias"]))
+    return torch.sigmoid(F.conv2d(r, rb(sd[f"{p}.se.conv_expand.weight"]), sd[f"{p}.se.conv_expand.bias"]))
 
 
 def forward_features(sd, x, sim_bf16=False, taps=None):

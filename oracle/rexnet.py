@@ -100,9 +100,17 @@ def forward_features(sd, x, width_mult, sim_bf16=False, taps=None):
         if b["rd"]:
             s = d.mean((2, 3), keepdim=True)
             bn = bn_of(sd, f"{p}.se.bn")
-            r = F.conv2d(s, sd[f"{p}.se.fc1.weight"], sd[f"{p}.se.fc1.bias"])
-            r = F.relu(F.batch_norm(r, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], False, 0.0, BN_EPS))
-            gate = torch.sigmoid(F.conv2d(r, sd[f"{p}.se.fc2.weight"], sd[f"{p}.se.fc2.bias"]))
+            if sim_bf16:
+                # the HIP path folds the SE BN into fc1 and stores both FC matrices rounded to bf16 (fp32 math)
+                scale = bn["weight"] / torch.sqrt(bn["running_var"] + BN_EPS)
+                w1 = rb(sd[f"{p}.se.fc1.weight"] * scale.reshape(-1, 1, 1, 1))
+                b1 = sd[f"{p}.se.fc1.bias"] * scale + (bn["bias"] - bn["running_mean"] * scale)
+                r = F.relu(F.conv2d(s, w1, b1))
+                gate = torch.sigmoid(F.conv2d(r, rb(sd[f"{p}.se.fc2.weight"]), sd[f"{p}.se.fc2.bias"]))
+            else:
+                r = F.conv2d(s, sd[f"{p}.se.fc1.weight"], sd[f"{p}.se.fc1.bias"])
+                r = F.relu(F.batch_norm(r, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], False, 0.0, BN_EPS))
+                gate = torch.sigmoid(F.conv2d(r, sd[f"{p}.se.fc2.weight"], sd[f"{p}.se.fc2.bias"]))
             x = rb(F.relu6(rb(d) * gate))
         else:
             x = rb(F.relu6(rb(d)))
