@@ -33,8 +33,8 @@ PROTOTYPES = {
     "mi355_pair_cosine": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_float, vp, vp]),
     "mi355_contrastive_loss": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_int, vp, vp, vp]),
     "mi355_cosine_embedding_loss": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_int, vp, vp]),
-    "mi355_hit_counts": (C.c_int, [vp, C.c_int64, C.c_int, vp, vp, vp, vp]),
-    "mi355_distinct_class_topn": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp, C.c_int, vp, vp, vp, vp]),
+    "mi355_hit_counts": (C.c_int, [vp, C.c_int64, C.c_int, vp, vp, C.c_int64, vp, vp]),
+    "mi355_distinct_class_topn": (C.c_int, [vp, vp, C.c_int64, C.c_int, vp, C.c_int64, C.c_int, vp, vp, vp, vp]),
     "mi355_model_create": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(vp)]),
     "mi355_model_destroy": (None, [vp]),
     "mi355_model_num_tensors": (C.c_int, [vp]),
@@ -48,6 +48,7 @@ PROTOTYPES = {
     "mi355_model_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "mi355_model_enable_taps": (C.c_int, [vp, C.c_int]),
     "mi355_model_read_tap": (C.c_int, [vp, C.c_char_p, vp, C.c_int64, C.POINTER(C.c_int64), vp]),
+    "mi355_model_run_between_taps": (C.c_int, [vp, C.c_char_p, C.c_char_p, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mi355_model_traffic": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mi355_model_traffic_kinds": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
@@ -83,8 +84,8 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)  # AttributeError here = header/library mismatch: fail loudly
             fn.restype = res
             fn.argtypes = args
-        if L.mi355_abi_version() != 1:
-            raise ImportError(f"ABI version mismatch: library {L.mi355_abi_version()} != binding 1")
+        if L.mi355_abi_version() != 2:
+            raise ImportError(f"ABI version mismatch: library {L.mi355_abi_version()} != binding 2")
         _lib = L
     return _lib
 

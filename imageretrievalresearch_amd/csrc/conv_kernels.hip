@@ -525,6 +525,31 @@ int launch_nhwc_to_nchw_f32(const bf16_t* in, float* out, int B, int HW, int C, 
     return OK;
 }
 
+// out[b][p][c] = bf16(in[b][c][p]) (zeros for c >= Cvalid); same 32x32 LDS transpose.  Parity tool (run_between_taps).
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float* __restrict__ in, bf16_t* __restrict__ out, int HW,
+                                                      int Cvalid, int C) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, p = p0 + tx;
+        tile[i][tx] = (c < Cvalid && p < HW) ? in[((size_t)b * Cvalid + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int p = p0 + i, c = c0 + tx;
+        if (p < HW && c < C) out[((size_t)b * HW + p) * C + c] = f2bf(tile[tx][i]);
+    }
+}
+
+int launch_nchw_f32_to_nhwc_bf16(const float* in, bf16_t* out, int B, int HW, int Cvalid, int C, hipStream_t st) {
+    dim3 grid(cdiv(HW, 32), cdiv(C, 32), B);
+    hipLaunchKernelGGL(k_nchw_to_nhwc, grid, dim3(256), 0, st, in, out, HW, Cvalid, C);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
 __global__ __launch_bounds__(256) void k_conv_input_silu(const float* __restrict__ x, const float* __restrict__ w,
                                                          float* __restrict__ out, int H, int W) {
     __shared__ float sw[81];

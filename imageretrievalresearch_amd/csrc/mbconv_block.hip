@@ -85,7 +85,7 @@ template <int KS> struct MbTaps {
 //   WRING  k-steps of expand weights a wave holds in registers = the largest Kp/32 the class supports: a whole slab's
 //          fragments are requested one phase ahead and the k-loop issues no loads (hipcc cannot count waits for
 //          loop-carried loads: every in-loop refill became a vmcnt(0), i.e. an exposed L2 round trip per k-step)
-//   A_IT   16-byte pieces of a 128-deep projection A chunk staged per thread
+//   A_IT   16-byte pieces of a projection A chunk (128 deep, 256 for the 7x7 class) staged per thread
 template <int KS, int S, int WI, int NWM, int CW, int MW, int NTW, int MWP, int WRING, int A_IT>
 __global__ __launch_bounds__(MB_THREADS) void k_mbconv_block(const BlockArgs a) {
     using TP = MbTaps<KS>;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(MB_THREADS) void k_mbconv_block(const BlockArgs a) 
     constexpr int NP = TP::NP;
     constexpr int EW = WI + 2 * PAD;                  // E image: zero columns left/right AND zero rows above/below
     constexpr int WO = (WI + 2 * PAD - KS) / S + 1;   // output width
-    constexpr int KC = 128;                           // projection K chunk
+    constexpr int KC = WI == 7 ? 256 : 128;           // projection K chunk (7x7 class: 64 rows, so twice as deep fits)
     constexpr int ALD = KC + 8;                       // projection A-chunk row stride
     static_assert(CTW >= 1 && CTW * 16 * MB_WAVES == MC, "phase 2: a wave owns whole 16-channel tiles");
     extern __shared__ __attribute__((aligned(16))) unsigned char mb_smem[];
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(MB_THREADS) void k_mbconv_block(const BlockArgs a) 
     bf16_t* Xs = reinterpret_cast<bf16_t*>(mb_smem);                       // [MT*16][XLD] (+ a zero tail)
     size_t off = ((size_t)MT * 16 * XLD * 2 + 64 + 15) & ~(size_t)15;
     float* pool = reinterpret_cast<float*>(mb_smem + off);                 // [mid] squeeze sums
-    off += (size_t)((a.mid + 127) & ~127) * 4;
+    off += (size_t)((a.mid + 255) & ~255) * 4;
     float* rvec = reinterpret_cast<float*>(mb_smem + off);                 // [rd]
     off += MB_MAX_RD * 4;
     unsigned char* R = mb_smem + off;
@@ -395,8 +395,8 @@ _Pragma("unroll")
     __syncthreads();      // full fence: the depthwise output (global) is re-read by other waves in the projection
     tick(8);
 
-        const float* gate = reinterpret_cast<const float*>(mb_smem);                                   // [ceil128(mid)]
-        bf16_t* As = reinterpret_cast<bf16_t*>(mb_smem + (size_t)((a.mid + 127) & ~127) * 4);          // [2][MTp*16][ALD]
+        const float* gate = reinterpret_cast<const float*>(mb_smem);                                   // [ceil256(mid)]
+        bf16_t* As = reinterpret_cast<bf16_t*>(mb_smem + (size_t)((a.mid + 255) & ~255) * 4);          // [2][MTp*16][ALD]
         const int MTp = (Pout + 15) >> 4, NTp = (a.Cout + 15) >> 4;
         const int ntw = mb_proj_ntw(NTp, MTp, NTW);           // column tiles per wave (<= NTW)
         const int nwn = (NTp + ntw - 1) / ntw;                // waves along N
@@ -433,7 +433,7 @@ _Pragma("unroll")
             for (int i = 0; i < A_IT; ++i) {
                 const int id = tid + i * MB_THREADS;
                 const int row = id / CPR, c = id - row * CPR;
-                const int k = chunk * KC + c * 8;                    // < ceil128(mid) = pool's padded size
+                const int k = chunk * KC + c * 8;                    // < ceil256(mid) = pool's padded size
                 const f32x4 g0 = *reinterpret_cast<const f32x4*>(&gate[k]);
                 const f32x4 g1 = *reinterpret_cast<const f32x4*>(&gate[k + 4]);
                 const u32x4 v = sreg[i];
@@ -520,10 +520,15 @@ _Pragma("unroll")
             if (JS > 1) break;
         }
         mb_lds_barrier();
+        // chunk 0 of the projection operands is requested here: it travels while the gate is reduced and the A buffers zeroed
+        a_load(0);
+#pragma unroll
+        for (int kk = 0; kk < KPC; ++kk) p_fetch(0, kk);
+        __builtin_amdgcn_sched_barrier(0);
         // the gate goes to the START of the LDS (the X image is dead: the residual is re-read from L2), so that the
         // projection's A double buffer can take everything behind it
         float* gate_w = reinterpret_cast<float*>(mb_smem);
-        for (int c = tid; c < ((a.mid + 127) & ~127); c += MB_THREADS) {
+        for (int c = tid; c < ((a.mid + 255) & ~255); c += MB_THREADS) {
             float g = 0.f;                                   // K tail of the last projection chunk: gate 0
             if (c < a.mid) {
                 g = a.b2[c];
@@ -547,9 +552,6 @@ _Pragma("unroll")
         }
         for (int id = tid; id < 2 * abuf / 8; id += MB_THREADS)
             *reinterpret_cast<u32x4*>(&As[id * 8]) = (u32x4){0u, 0u, 0u, 0u};
-        a_load(0);
-#pragma unroll
-        for (int kk = 0; kk < KPC; ++kk) p_fetch(0, kk);
         mb_lds_barrier();          // As zeroed
         a_store(0);
         if (nchunks > 1) a_load(1);
@@ -663,7 +665,7 @@ _Pragma("unroll")
 // ------------------------------------------------------------------------------------------ host side
 struct MbGeom { int wi, nwm, cw, mw, ntw, mwp, mc, wring, a_it; };
 static bool mb_geom(int H, int W, MbGeom* g) {
-    if (W == 7 && H * W <= 64) { *g = {7, 1, 2, 4, 3, 4, 256, 12, 2}; return true; }
+    if (W == 7 && H * W <= 64) { *g = {7, 1, 2, 4, 3, 4, 256, 12, 4}; return true; }
     if (W == 14 && H * W <= 208) { *g = {14, 2, 2, 7, 3, 7, 128, 5, 7}; return true; }
     return false;
 }
@@ -672,7 +674,7 @@ static bool mb_geom(int H, int W, MbGeom* g) {
 static size_t mb_lds_bytes_xld(const BlockArgs& a, int k, int xld, const MbGeom& g) {
     const int P = a.H * a.W, MT = (P + 15) / 16, pad = k / 2;
     const int EP = ((a.H + 2 * pad) * (a.W + 2 * pad) + 8 + 7) & ~7;
-    const size_t xs = ((size_t)MT * 16 * xld * 2 + 64 + 15) & ~(size_t)15, pl = (size_t)((a.mid + 127) & ~127) * 4;
+    const size_t xs = ((size_t)MT * 16 * xld * 2 + 64 + 15) & ~(size_t)15, pl = (size_t)((a.mid + 255) & ~255) * 4;
     const size_t fixed = xs + pl + MB_MAX_RD * 4;
     const size_t slab = (size_t)EP * (g.mc + 8) * 2;
     const int Pout = a.Ho * a.Wo, MTp = (Pout + 15) / 16;
@@ -681,7 +683,8 @@ static size_t mb_lds_bytes_xld(const BlockArgs& a, int k, int xld, const MbGeom&
     if (JS > 8) JS = 8;
     if (JS < 1) JS = 1;
     const size_t se = (size_t)JS * a.mid * 4;
-    const size_t proj = pl + (size_t)2 * MTp * 16 * (128 + 8) * 2;           // gate, then the A double buffer
+    const int kc = g.wi == 7 ? 256 : 128;
+    const size_t proj = pl + (size_t)2 * MTp * 16 * (kc + 8) * 2;            // gate, then the A double buffer
     size_t r = slab;
     if (se > r) r = se;
     const size_t total = fixed + r > proj ? fixed + r : proj;
@@ -714,7 +717,7 @@ bool mbconv_block_supported(int H, int W, int Cin, int mid, int Cout, int k, int
     int msplit = MB_WAVES / nwn;
     if (msplit > MTp) msplit = MTp;
     if ((MTp + msplit - 1) / msplit > g.mwp) return false;
-    if (Pout * 16 > g.a_it * MB_THREADS) return false;           // staged pieces per thread per 128-deep chunk
+    if (Pout * (g.wi == 7 ? 32 : 16) > g.a_it * MB_THREADS) return false;   // staged pieces per thread per K chunk
     if ((H * W + 15) / 16 > g.nwm * g.mw) return false;
     if (a.Kp / 32 > g.wring) return false;
     // register budget (hipcc spills, and a spill reload waits for every prefetch in flight): the 7x7 class with a 5x5
@@ -745,8 +748,8 @@ static int launch_mb(BlockArgs a, int B, hipStream_t st) {
 template <int KS, int S>
 static int launch_mb_ks(const BlockArgs& a, int B, hipStream_t st) {
     if (a.W == 7) {
-        if (a.Kp <= 256) return launch_mb<KS, S, 7, 1, 2, 4, 3, 4, 8, 2>(a, B, st);
-        return launch_mb<KS, S, 7, 1, 2, 4, 3, 4, 12, 2>(a, B, st);
+        if (a.Kp <= 256) return launch_mb<KS, S, 7, 1, 2, 4, 3, 4, 8, 4>(a, B, st);
+        return launch_mb<KS, S, 7, 1, 2, 4, 3, 4, 12, 4>(a, B, st);
     }
     if (a.Kp <= 96) return launch_mb<KS, S, 14, 2, 2, 7, 3, 7, 3, 7>(a, B, st);
     return launch_mb<KS, S, 14, 2, 2, 7, 3, 7, 5, 7>(a, B, st);

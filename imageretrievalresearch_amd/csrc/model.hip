@@ -360,12 +360,13 @@ static int exec_fused(ExecCtx& cx, const Op& g, const Op& d) {
     return launch_fused_band(a, cx.nb, d.k, d.stride, cx.st);
 }
 
-static int run_backbone(ExecCtx& cx) {
+static int run_backbone(ExecCtx& cx, size_t op_begin = 0, size_t op_end = (size_t)-1) {
     mi355_model* m = cx.m;
     // NOTE: slot dims for DW/SE depend on walk order; plan_slots() left the LAST writer's dims in each
     // slot, so re-derive dims incrementally while executing.
     SlotState* S = m->slots;
-    for (size_t oi = 0; oi < m->def.ops.size(); ++oi) {
+    if (op_end > m->def.ops.size()) op_end = m->def.ops.size();
+    for (size_t oi = op_begin; oi < op_end; ++oi) {
         const Op& op = m->def.ops[oi];
         const int op_index = (int)oi;
         const int in_h = S[op.in == SLOT_NONE ? 0 : op.in].h, in_w = S[op.in == SLOT_NONE ? 0 : op.in].w;
@@ -431,13 +432,37 @@ static int forward_impl(mi355_model* m, const float* x, int B, int H, int W, flo
     MI355_REQUIRE(B >= 1 && H >= 32 && W >= 32, "forward: bad shape B=%d H=%d W=%d", B, H, W);
     const ModelDef& d = m->def;
     if (d.pools_in_features) MI355_REQUIRE(H == 224 && W == 224, "forward: %s needs 224x224 input", d.arch.c_str());
-    const int mb = (m->microbatch > 0 && m->microbatch < B) ? m->microbatch : B;
+    // Chunking.  "lanes" > 1: the batch is cut into that many chunks which run CONCURRENTLY on internal streams (forked from
+    // and joined back into the caller's stream with events), each with its own copy of the arena: the early layers are
+    // HBM-bound and the late ones VALU-bound, so two half-batches a few kernels apart keep both busy where one
+    // batch alternates between them.  Results do not depend on the chunking (every kernel is batch-position invariant).
+    int nl = m->lanes;
+    if (nl > 4) nl = 4;
+    if (nl < 1 || B < 32 * nl || m->profile || m->taps) nl = 1;
+    int mb = (m->microbatch > 0 && m->microbatch < B) ? m->microbatch : B;
+    if (nl > 1) mb = (B + nl - 1) / nl;
     const size_t bytes = plan_slots(m, mb, H, W);
-    if (int e = ensure_arena(m, bytes)) return e;
+    m->lane_bytes = nl > 1 ? align_up(bytes, 4096) : 0;
+    if (int e = ensure_arena(m, nl > 1 ? m->lane_bytes * nl : bytes)) return e;
+    if (nl > 1) {
+        if (!m->lane_fork) MI355_CHECK_HIP(hipEventCreateWithFlags(&m->lane_fork, hipEventDisableTiming));
+        for (int l = 0; l < nl; ++l) {
+            if (!m->lane_stream[l]) MI355_CHECK_HIP(hipStreamCreateWithFlags(&m->lane_stream[l], hipStreamNonBlocking));
+            if (!m->lane_join[l]) MI355_CHECK_HIP(hipEventCreateWithFlags(&m->lane_join[l], hipEventDisableTiming));
+        }
+        MI355_CHECK_HIP(hipEventRecord(m->lane_fork, st));
+    }
+    hipStream_t caller_st = st;
+    int lane = 0;
     const int D = d.feat_dim, Dp = d.feat_dim_pad;
-    for (int b0 = 0; b0 < B; b0 += mb) {
+    for (int b0 = 0; b0 < B; b0 += mb, ++lane) {
         const int nb = std::min(mb, B - b0);
+        if (nl > 1) {
+            st = m->lane_stream[lane];
+            MI355_CHECK_HIP(hipStreamWaitEvent(st, m->lane_fork, 0));
+        }
         ExecCtx cx{m, st, nb, H, W, x + (size_t)b0 * 3 * H * W, b0, B};
+        cx.lane = nl > 1 ? lane : 0;
         if (int e = run_backbone(cx)) return e;
         const SlotState& F = m->slots[d.final_slot];
         const int hw = F.h * F.w;
@@ -482,6 +507,10 @@ static int forward_impl(mi355_model* m, const float* x, int B, int H, int W, flo
             a.zeros = (const bf16_t*)cx.w(0);
             if (int e = launch_gemm_bf16(a, st)) return e;
         }
+        if (nl > 1) {
+            MI355_CHECK_HIP(hipEventRecord(m->lane_join[lane], st));
+            MI355_CHECK_HIP(hipStreamWaitEvent(caller_st, m->lane_join[lane], 0));
+        }
     }
     return OK;
 }
@@ -520,6 +549,11 @@ void mi355_model_destroy(mi355_model_t m) {
     if (m->dev_blob) (void)hipFree(m->dev_blob);
     if (m->arena) (void)hipFree(m->arena);
     if (m->stamp_buf) (void)hipFree(m->stamp_buf);
+    for (int l = 0; l < 4; ++l) {
+        if (m->lane_stream[l]) (void)hipStreamDestroy(m->lane_stream[l]);
+        if (m->lane_join[l]) (void)hipEventDestroy(m->lane_join[l]);
+    }
+    if (m->lane_fork) (void)hipEventDestroy(m->lane_fork);
     for (auto& kv : m->tapbufs)
         if (kv.second.ptr) (void)hipFree(kv.second.ptr);
     delete m;
@@ -590,6 +624,46 @@ int mi355_model_forward(mi355_model_t m, const float* x, int B, int H, int W, fl
     return forward_impl(m, x, B, H, W, out, pooled_out, false, (hipStream_t)stream);
 }
 
+// Parity tool: run ONLY the ops behind tap `from_tap` up to and including the op that records tap `to_tap`, on an activation
+// supplied by the caller (x: [B][C][h][w] fp32 NCHW, rounded to bf16 on the way in - feed it the oracle's bf16-rounded tap
+// of the previous layer).  Taps are recorded as in a normal forward (enable them first), so each layer / block can be
+// compared with the oracle on the ORACLE's input: errors do not compound through the network.
+int mi355_model_run_between_taps(mi355_model_t m, const char* from_tap, const char* to_tap, const float* x, int B, int C,
+                                 int h, int w, void* stream) {
+    MI355_REQUIRE(m && from_tap && to_tap && x, "run_between_taps: null argument");
+    MI355_REQUIRE(m->packed, "run_between_taps: weights not packed");
+    MI355_REQUIRE(B >= 1 && C >= 1 && h >= 1 && w >= 1, "run_between_taps: bad shape");
+    const auto& ops = m->def.ops;
+    size_t i0 = ops.size(), i1 = ops.size();
+    for (size_t i = 0; i < ops.size(); ++i) {
+        if (ops[i].tap == from_tap) i0 = i;
+        if (ops[i].tap == to_tap) i1 = i;
+    }
+    MI355_REQUIRE(i0 < ops.size() && i1 < ops.size() && i0 < i1, "run_between_taps: taps '%s' -> '%s' not found in that order",
+                  from_tap, to_tap);
+    const Op& src = ops[i0];
+    MI355_REQUIRE(src.out != SLOT_NONE && (src.cout_real ? src.cout_real : src.cout) == C,
+                  "run_between_taps: tap '%s' has %d channels, got %d", from_tap, src.cout_real ? src.cout_real : src.cout, C);
+    hipStream_t st = (hipStream_t)stream;
+    // size the arena as for a full forward whose maps are at least as large as the ones reached from here
+    int H = 32, W = 32;
+    for (const Op& op : ops) { (void)op; }
+    {   // input size that gives the tap this resolution: walk the strides in front of it
+        int sh = 1;
+        for (size_t i = 0; i <= i0; ++i)
+            if (ops[i].kind == OP_STEM || (ops[i].kind == OP_DW && ops[i].stride == 2)) sh *= 2;
+        H = h * sh; W = w * sh;
+    }
+    const size_t bytes = plan_slots(m, B, H, W);
+    m->lane_bytes = 0;
+    if (int e = ensure_arena(m, bytes)) return e;
+    ExecCtx cx{m, st, B, H, W, nullptr, 0, B};
+    SlotState* S = m->slots;
+    S[src.out].h = h; S[src.out].w = w; S[src.out].c = src.cout;
+    if (int e = launch_nchw_f32_to_nhwc_bf16(x, (bf16_t*)cx.slot_ptr(src.out), B, h * w, C, src.cout, st)) return e;
+    return run_backbone(cx, i0 + 1, i1 + 1);
+}
+
 int mi355_model_enable_taps(mi355_model_t m, int enable) {
     MI355_REQUIRE(m, "enable_taps: null model");
     m->taps = enable != 0;
@@ -612,6 +686,7 @@ int mi355_model_set_option(mi355_model_t m, const char* key, int64_t value) {
     MI355_REQUIRE(m && key, "set_option: null argument");
     const std::string k = key;
     if (k == "microbatch") m->microbatch = (int)value;
+    else if (k == "lanes") m->lanes = (int)value;
     else if (k == "fuse") m->fuse = value != 0;
     else if (k == "fuse_band") m->fuse_band = (int)value;
     else if (k == "fuse_debug") m->fuse_debug = (int)value;

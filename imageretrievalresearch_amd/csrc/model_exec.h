@@ -51,6 +51,10 @@ struct mi355_model {
     size_t arena_bytes = 0;
     SlotState slots[SLOT_COUNT];
     int microbatch = 0;
+    int lanes = 1;              // option "lanes": chunks of a forward run concurrently on this many internal HIP streams (1 = caller's stream only)
+    hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t lane_fork = nullptr, lane_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t lane_bytes = 0;      // arena bytes per lane
     int fuse_band = 2;          // band variant for the early stages: 0 never, 1 wherever it fits, 2 (default) only the shape
                                 // classes where it was measured faster than the unfused pair (see can_fuse in model.hip)
     bool fuse = true;           // fused expand+depthwise for whole-image tiles (option "fuse")
@@ -81,7 +85,8 @@ struct ExecCtx {
     int nb, H, W;          // chunk batch, input size
     const float* x;        // chunk input (NCHW fp32)
     int b0, B;             // chunk offset / full batch (for taps)
-    char* base() const { return (char*)m->arena; }
+    int lane = 0;          // which arena copy / internal stream this chunk uses
+    char* base() const { return (char*)m->arena + (size_t)lane * m->lane_bytes; }
     void* slot_ptr(int s) const { return s == SLOT_NONE ? nullptr : base() + m->slots[s].off; }
     const char* w(size_t off) const { return (const char*)m->dev_blob + off; }
 };

@@ -88,6 +88,8 @@ int launch_gap(const bf16_t* in, float* pooled, bf16_t* pooled_bf16, int B, int 
 
 // NHWC bf16 [B][HW][C] -> NCHW fp32 [B][Cvalid][HW] (forward_features output, taps).
 int launch_nhwc_to_nchw_f32(const bf16_t* in, float* out, int B, int HW, int C, int Cvalid, hipStream_t st);
+// NCHW fp32 [B][Cvalid][HW] -> NHWC bf16 [B][HW][C] (channels >= Cvalid are written as zeros); parity tool.
+int launch_nchw_f32_to_nhwc_bf16(const float* in, bf16_t* out, int B, int HW, int Cvalid, int C, hipStream_t st);
 
 // SquarePad + ToTensor + Normalize: uint8 HWC (h, w, 3) -> fp32 CHW (3, S, S), S = max(h, w); mean/std are HOST arrays.
 int launch_square_pad_normalize(const unsigned char* img, int h, int w, int fill, const float* mean, const float* stdv,

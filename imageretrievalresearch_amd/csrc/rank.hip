@@ -61,6 +61,35 @@ __global__ __launch_bounds__(256) void k_row_norm(const float* __restrict__ in, 
 static inline int vec_ok(const void* p, int dim) { return (dim % 4 == 0) && (((uintptr_t)p & 15) == 0); }
 
 // =====================================================================================
+// top-k selection
+// =====================================================================================
+// Ordering of (score, index) candidates: higher score first, ties -> lower index.  NaN orders as the LARGEST value, as in
+// torch.topk (a NaN score - e.g. from an Inf/NaN embedding - is returned with its in-range index instead of starving
+// the list and leaving pad entries behind); two NaNs tie.
+__device__ __forceinline__ bool better(float a, i64 ia, float b, i64 ib) {
+    const bool an = a != a, bn = b != b;
+    if (an || bn) return (an && !bn) || (an && bn && ia < ib);
+    return (a > b) || (a == b && ia < ib);
+}
+
+constexpr float NEG_INF = -INFINITY;
+constexpr i64 IDX_PAD = LLONG_MAX;
+
+constexpr int IDX32_PAD = INT_MAX;   // missing candidate in the fused per-tile lists (local int32 indices)
+
+// Order-preserving map float -> uint32 for the fused selection: larger key = better score.  NaN maps to the largest key
+// (torch.topk's order), -0 to the key of +0 (they compare equal as floats), every real score to a key > 0.
+__device__ __forceinline__ unsigned score_key(float x) {
+    const unsigned u = __float_as_uint(x + 0.0f);                  // -0 -> +0
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;       // NaN
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_score(unsigned key) {
+    if (key == 0xffffffffu) return __uint_as_float(0x7fc00000u);   // canonical NaN
+    return __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
+}
+
+// =====================================================================================
 // cosine GEMM:  S[q][g] = sum_d Qn[q][d] * Gal[g][d] * (ginv ? ginv[g] : 1)
 // =====================================================================================
 // Block = 4 waves as 2(M) x 2(N); wave tile = (MT*32) queries x 64 gallery rows; block tile =
@@ -70,10 +99,16 @@ static inline int vec_ok(const void* p, int dim) { return (dim % 4 == 0) && (((u
 // permutation, which only reorders the (exact) fma chain.
 constexpr int RK_BN = 128;
 
-template <int MT, int RK_BK, bool VEC>
+// FK = 0: write the score slab S.  FK = 1/2/4/8 (fused selection, k <= FK): the score tile never leaves the CU - it is
+// transposed through LDS (the staging buffers are free after the K loop), each of the tile's query rows is scanned by one
+// thread in ascending column order into a sorted FK-list, and k (score, local int32 index) candidates per (query, column
+// tile) go to cand_val / cand_idx [Q][n_tiles][k]; the existing multi-level selection then merges Q x n_tiles x k
+// candidates instead of reading Q x G scores (train/train.py:250-251 semantics, same tie rule).
+template <int MT, int RK_BK, bool VEC, int FK>
 __global__ __launch_bounds__(256) void k_cos_gemm(const float* __restrict__ Qn, const float* __restrict__ Gal,
                                                   const float* __restrict__ ginv, float* __restrict__ S,
-                                                  int Q, i64 G, int D) {
+                                                  int Q, i64 G, int D, int k, float* __restrict__ cand_val,
+                                                  int* __restrict__ cand_idx) {
     constexpr int BM = 64 * MT;
     constexpr int RK_LD = RK_BK + 4;      // +4 floats: ds_read_b128 of 16 distinct rows is bank-conflict free (36 and 20)
     constexpr int CPR = RK_BK / 4;        // float4 columns per row of a K-tile
@@ -183,6 +218,88 @@ __global__ __launch_bounds__(256) void k_cos_gemm(const float* __restrict__ Qn, 
         __syncthreads();
     }
 
+    if constexpr (FK > 0) {
+        // (the loop's last __syncthreads() retired every read of the staging buffers)
+        // 64 query rows at a time, so that the transposed tile (64 x 132 floats = 33.8 KB) fits inside the staging
+        // buffers: a bigger LDS request would cost the third resident workgroup per CU and with it a round of tiles
+        constexpr int CLD = RK_BN + 4;                 // 132 floats: a thread per row reads float4s conflict-free
+        float* Ct = smem;                              // [64][CLD]
+        const i64 ncol = (G - n0 < RK_BN) ? G - n0 : RK_BN;     // valid columns of this tile
+#pragma unroll 1
+        for (int h = 0; h < BM / 64; ++h) {
+            if ((wm * MT * 32) / 64 == h) {            // this wave's rows belong to pass h
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const i64 col = n0 + wn * 64 + j * 32 + lr;
+                    const float gs = (ginv && col < G) ? ginv[col] : 1.0f;
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = (wm * MT * 32) % 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                            Ct[row * CLD + wn * 64 + j * 32 + lr] = acc[i][j][r] * gs;
+                        }
+                }
+            }
+            __syncthreads();
+            // Selection: FOUR threads per query row, each scans 32 columns in ascending order into a sorted FK-list held as
+            // order-preserving integer keys (NaN = largest, -0 = +0); the insertion is branch-free (a divergent insertion
+            // sort cost 10 % of the tile: some lane of the wave inserts at almost every column) and skipped by a wave vote
+            // when no lane beats its FK-th entry.  The row's four lists are merged through shuffles in column order, so
+            // ties keep resolving to the lower index.
+            {
+                const int lrow = tid >> 2, part = tid & 3;
+                unsigned kv[FK];
+                int ki[FK];
+#pragma unroll
+                for (int i = 0; i < FK; ++i) { kv[i] = 0u; ki[i] = IDX32_PAD; }      // key 0 = below every real score (-inf is 0x007fffff)
+                auto insert = [&](unsigned key, int id) {
+                    bool g[FK];
+#pragma unroll
+                    for (int i = 0; i < FK; ++i) g[i] = key > kv[i];          // strict: an equal score keeps the earlier (lower) index
+#pragma unroll
+                    for (int i = FK - 1; i > 0; --i) {
+                        kv[i] = g[i] ? (g[i - 1] ? kv[i - 1] : key) : kv[i];
+                        ki[i] = g[i] ? (g[i - 1] ? ki[i - 1] : id) : ki[i];
+                    }
+                    kv[0] = g[0] ? key : kv[0];
+                    ki[0] = g[0] ? id : ki[0];
+                };
+                const float* rowp = Ct + lrow * CLD + part * 32;
+#pragma unroll 2
+                for (int c4i = 0; c4i < 8; ++c4i) {
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(rowp + c4i * 4);
+                    const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = part * 32 + c4i * 4 + e;
+                        unsigned key = score_key(vv[e]);
+                        if (c >= ncol) key = 0u;
+                        if (__any(key > kv[FK - 1])) insert(key, (int)n0 + c);      // n0 + c < 2^31 (checked on the host)
+                    }
+                }
+                // merge parts 1..3 into part 0 (lanes 4r .. 4r+3 of one wave)
+#pragma unroll
+                for (int src = 1; src < 4; ++src) {
+#pragma unroll
+                    for (int i = 0; i < FK; ++i) {
+                        const unsigned ok = (unsigned)__shfl(kv[i], (lane & ~3) + src, 64);
+                        const int oi = __shfl(ki[i], (lane & ~3) + src, 64);
+                        if (part == 0) insert(ok, oi);
+                    }
+                }
+                const int qrow = m0 + h * 64 + lrow;
+                if (part == 0 && qrow < Q) {
+                    const size_t o = ((size_t)qrow * gridDim.x + blockIdx.x) * k;
+#pragma unroll
+                    for (int i = 0; i < FK; ++i)
+                        if (i < k) { cand_val[o + i] = ki[i] == IDX32_PAD ? NEG_INF : key_score(kv[i]); cand_idx[o + i] = ki[i]; }
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
     // epilogue: C[row = query][col = gallery]; lane: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -247,21 +364,13 @@ __global__ __launch_bounds__(256) void k_cos_gemv(const float* __restrict__ Qn, 
     }
 }
 
-// =====================================================================================
-// top-k selection
-// =====================================================================================
-__device__ __forceinline__ bool better(float a, i64 ia, float b, i64 ib) {
-    return (a > b) || (a == b && ia < ib);
-}
-
-constexpr float NEG_INF = -INFINITY;
-constexpr i64 IDX_PAD = LLONG_MAX;
-
 // ---- small k (<= 8): per-thread sorted list in registers, then k rounds of block arg-max.
 // grid = (nchunk, Q).  Input row q: vals[q*in_stride + j], j in [0,rowlen); implicit index j (+offset)
 // when idxs == nullptr.  Output: out[(q*nchunk + chunk)*k + r].
+// idxs32 (optional): int32 LOCAL indices from the fused GEMM epilogue (IDX32_PAD = missing); idx_offset is added to them.
 template <int K>
 __global__ __launch_bounds__(256) void k_topk_small(const float* __restrict__ vals, const i64* __restrict__ idxs,
+                                                    const int* __restrict__ idxs32,
                                                     i64 rowlen, i64 in_stride, i64 chunk_len, int k,
                                                     i64 idx_offset, float* __restrict__ ov, i64* __restrict__ oi) {
     const int tid = threadIdx.x;
@@ -270,6 +379,7 @@ __global__ __launch_bounds__(256) void k_topk_small(const float* __restrict__ va
     const i64 c1 = min(rowlen, c0 + chunk_len);
     const float* v = vals + q * in_stride;
     const i64* ix = idxs ? idxs + q * in_stride : nullptr;
+    const int* ix32 = idxs32 ? idxs32 + q * in_stride : nullptr;
 
     float lv[K];
     i64 li[K];
@@ -278,8 +388,10 @@ __global__ __launch_bounds__(256) void k_topk_small(const float* __restrict__ va
 
     for (i64 j = c0 + tid; j < c1; j += 256) {
         const float x = v[j];
-        const i64 id = ix ? ix[j] : j + idx_offset;
-        if (better(x, id, lv[K - 1], li[K - 1])) {
+        i64 id;
+        if (ix32) { const int t = ix32[j]; id = t == IDX32_PAD ? IDX_PAD : (i64)t + idx_offset; }
+        else id = ix ? ix[j] : j + idx_offset;
+        if (id != IDX_PAD && better(x, id, lv[K - 1], li[K - 1])) {
             lv[K - 1] = x; li[K - 1] = id;
 #pragma unroll
             for (int i = K - 1; i > 0; --i) {
@@ -313,7 +425,7 @@ __global__ __launch_bounds__(256) void k_topk_small(const float* __restrict__ va
             if (better(sv[w], si[w], bv, bi)) { bv = sv[w]; bi = si[w]; }
         if (tid == 0) { o_v[r] = bv; o_i[r] = bi; }
         // the owner pops its head (indices are unique among real entries; pads never win a real slot)
-        if (li[0] == bi && lv[0] == bv && bi != IDX_PAD) {
+        if (li[0] == bi && bi != IDX_PAD) {      // (by index only: a NaN score does not compare equal to itself)
 #pragma unroll
             for (int i = 0; i < K - 1; ++i) { lv[i] = lv[i + 1]; li[i] = li[i + 1]; }
             lv[K - 1] = NEG_INF; li[K - 1] = IDX_PAD;
@@ -443,14 +555,19 @@ __global__ __launch_bounds__(1024) void k_cos_embedding_loss(const float* __rest
     }
 }
 
+// An index outside [0, G) (a pad entry of a list with fewer than k real candidates) counts as a miss.
 __global__ void k_hit_counts(const i64* __restrict__ idx, i64 Q, int k, const i64* __restrict__ qcls,
-                             const i64* __restrict__ gcls, i64* __restrict__ counts) {
+                             const i64* __restrict__ gcls, i64 G, i64* __restrict__ counts) {
     const i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     int h1 = 0, h3 = 0;
     if (q < Q) {
         const i64 c = qcls[q];
-        h1 = (gcls[idx[q * k]] == c);
-        for (int j = 0; j < min(k, 3); ++j) h3 |= (gcls[idx[q * k + j]] == c);
+        for (int j = 0; j < min(k, 3); ++j) {
+            const i64 g = idx[q * k + j];
+            const int hit = (g >= 0 && g < G) ? (gcls[g] == c) : 0;
+            if (j == 0) h1 = hit;
+            h3 |= hit;
+        }
     }
     // integer atomics: order-independent
     const unsigned long long m1 = __ballot(h1), m3 = __ballot(h3);
@@ -461,7 +578,7 @@ __global__ void k_hit_counts(const i64* __restrict__ idx, i64 Q, int k, const i6
 }
 
 __global__ void k_distinct_topn(const i64* __restrict__ idx, const float* __restrict__ val, i64 Q, int k,
-                                const i64* __restrict__ gcls, int n, i64* __restrict__ ocls,
+                                const i64* __restrict__ gcls, i64 G, int n, i64* __restrict__ ocls,
                                 i64* __restrict__ oidx, float* __restrict__ oval) {
     const i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= Q) return;
@@ -470,6 +587,7 @@ __global__ void k_distinct_topn(const i64* __restrict__ idx, const float* __rest
     for (int j = 0; j < n; ++j) { ocls[q * n + j] = -1; oidx[q * n + j] = -1; oval[q * n + j] = NAN; }
     for (int j = 0; j < k && ns < n; ++j) {
         const i64 g = idx[q * k + j];
+        if (g < 0 || g >= G) continue;          // pad entry: not a candidate
         const i64 c = gcls[g];
         bool dup = false;
 #pragma unroll
@@ -506,24 +624,27 @@ static size_t topk_ws_bytes(i64 Q, i64 G, int k) {
 }
 
 template <int K>
-static void launch_small(const float* v, const i64* ix, i64 rowlen, i64 in_stride, i64 chunk_len, int k,
+static void launch_small(const float* v, const i64* ix, const int* ix32, i64 rowlen, i64 in_stride, i64 chunk_len, int k,
                          i64 off, float* ov, i64* oi, i64 nchunk, i64 Q, hipStream_t st) {
-    hipLaunchKernelGGL((k_topk_small<K>), dim3((unsigned)nchunk, (unsigned)Q), dim3(256), 0, st, v, ix, rowlen,
+    hipLaunchKernelGGL((k_topk_small<K>), dim3((unsigned)nchunk, (unsigned)Q), dim3(256), 0, st, v, ix, ix32, rowlen,
                        in_stride, chunk_len, k, off, ov, oi);
 }
-static void dispatch_small(const float* v, const i64* ix, i64 rowlen, i64 in_stride, i64 chunk_len, int k,
+static void dispatch_small(const float* v, const i64* ix, const int* ix32, i64 rowlen, i64 in_stride, i64 chunk_len, int k,
                            i64 off, float* ov, i64* oi, i64 nchunk, i64 Q, hipStream_t st) {
-    if (k <= 1) launch_small<1>(v, ix, rowlen, in_stride, chunk_len, k, off, ov, oi, nchunk, Q, st);
-    else if (k <= 2) launch_small<2>(v, ix, rowlen, in_stride, chunk_len, k, off, ov, oi, nchunk, Q, st);
-    else if (k <= 4) launch_small<4>(v, ix, rowlen, in_stride, chunk_len, k, off, ov, oi, nchunk, Q, st);
-    else launch_small<8>(v, ix, rowlen, in_stride, chunk_len, k, off, ov, oi, nchunk, Q, st);
+    if (k <= 1) launch_small<1>(v, ix, ix32, rowlen, in_stride, chunk_len, k, off, ov, oi, nchunk, Q, st);
+    else if (k <= 2) launch_small<2>(v, ix, ix32, rowlen, in_stride, chunk_len, k, off, ov, oi, nchunk, Q, st);
+    else if (k <= 4) launch_small<4>(v, ix, ix32, rowlen, in_stride, chunk_len, k, off, ov, oi, nchunk, Q, st);
+    else launch_small<8>(v, ix, ix32, rowlen, in_stride, chunk_len, k, off, ov, oi, nchunk, Q, st);
 }
 
 // Select top-k of each row of vals[Q][rowlen] (implicit or explicit indices) into out_val/out_idx [Q][k].
+// idxs32 (with idxs == nullptr): int32 local candidate indices of the fused GEMM epilogue, k <= SMALL_K only.
 static int topk_select(const float* vals, const i64* idxs, i64 Q, i64 rowlen, i64 in_stride, int k, i64 idx_offset,
-                       float* out_val, i64* out_idx, void* ws, size_t ws_bytes, hipStream_t st) {
+                       float* out_val, i64* out_idx, void* ws, size_t ws_bytes, hipStream_t st,
+                       const int* idxs32 = nullptr) {
     MI355_REQUIRE(k >= 1 && k <= LARGE_K, "top-k: k=%d outside [1,%d]", k, LARGE_K);
     MI355_REQUIRE(k <= rowlen, "top-k: k=%d exceeds row length %lld", k, (long long)rowlen);
+    MI355_REQUIRE(!idxs32 || k <= SMALL_K, "top-k: int32 candidate lists need k <= %d", SMALL_K);
     MI355_REQUIRE(Q >= 1 && Q <= 65535 * 16, "top-k: Q=%lld out of range", (long long)Q);
     MI355_REQUIRE(ws_bytes >= topk_ws_bytes(Q, rowlen, k), "top-k: workspace %zu < %zu bytes", ws_bytes,
                   topk_ws_bytes(Q, rowlen, k));
@@ -541,6 +662,7 @@ static int topk_select(const float* vals, const i64* idxs, i64 Q, i64 rowlen, i6
         const i64 qn = (Q - qs < 65535) ? Q - qs : 65535;
         const float* v = vals + qs * in_stride;
         const i64* ix = idxs ? idxs + qs * in_stride : nullptr;
+        const int* ix32 = idxs32 ? idxs32 + qs * in_stride : nullptr;
         i64 len = rowlen, stride = in_stride;
         i64 off = idx_offset;
         int cur = 0;
@@ -551,12 +673,12 @@ static int topk_select(const float* vals, const i64* idxs, i64 Q, i64 rowlen, i6
             const bool last = (nchunk == 1);
             float* ovp = last ? out_val + qs * k : cv[cur];
             i64* oip = last ? out_idx + qs * k : ci[cur];
-            if (small) dispatch_small(v, ix, len, stride, chunk, k, off, ovp, oip, nchunk, qn, st);
+            if (small) dispatch_small(v, ix, ix32, len, stride, chunk, k, off, ovp, oip, nchunk, qn, st);
             else hipLaunchKernelGGL(k_topk_bitonic, dim3((unsigned)nchunk, (unsigned)qn), dim3(256), 0, st, v, ix,
                                     len, stride, k, off, ovp, oip);
             MI355_LAUNCH_CHECK();
             if (last) break;
-            v = cv[cur]; ix = ci[cur];
+            v = cv[cur]; ix = ci[cur]; ix32 = nullptr;
             len = nchunk * k; stride = len; off = 0;
             cur ^= 1;
         }
@@ -564,7 +686,16 @@ static int topk_select(const float* vals, const i64* idxs, i64 Q, i64 rowlen, i6
     return OK;
 }
 
-static i64 query_block(i64 Q, i64 G) {
+static bool fused_select(i64 Q, i64 G, int k) { return k >= 1 && k <= SMALL_K && Q > 4 && G < ((i64)1 << 31) - RK_BN; }
+
+static i64 query_block(i64 Q, i64 G, int k) {
+    if (fused_select(Q, G, k)) {
+        // no score slab: candidates are cdiv(G,128) * k * 8 B per query; keep them <= 256 MiB per block of queries
+        i64 qb = ((i64)1 << 28) / (cdiv(G, RK_BN) * (i64)k * 8);
+        qb = qb / 128 * 128;
+        if (qb < 128) qb = 128;
+        return qb < Q ? qb : Q;
+    }
     // keep the score slab S[qb][G] around <= 1 GiB, in multiples of 256 queries
     i64 qb = ((i64)1 << 28) / (G > 0 ? G : 1);
     qb = qb / 256 * 256;
@@ -573,45 +704,69 @@ static i64 query_block(i64 Q, i64 G) {
 }
 
 struct RankWs {
-    float* qn; float* ginv; float* S; void* topk; size_t topk_bytes; size_t total;
+    float* qn; float* ginv; float* S; float* cand_val; int* cand_idx; void* topk; size_t topk_bytes; size_t total;
 };
 static RankWs carve(void* ws, i64 Q, i64 G, int D, int k, bool need_ginv, bool need_S = true) {
     RankWs r{};
-    const i64 qb = query_block(Q, G);
+    const bool fused = need_S && fused_select(Q, G, k);
+    const i64 qb = query_block(Q, G, need_S ? k : 0);
     size_t off = 0;
     char* base = ws ? (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255) : nullptr;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
     r.qn = (float*)take((size_t)Q * D * sizeof(float));
     r.ginv = (float*)take(need_ginv ? (size_t)G * sizeof(float) : 0);
-    r.S = (float*)take(need_S ? (size_t)qb * G * sizeof(float) : 0);
-    r.topk_bytes = k > 0 ? topk_ws_bytes(qb, G, k) : 0;
+    if (fused) {
+        const size_t ncand = (size_t)qb * cdiv(G, RK_BN) * k;
+        r.cand_val = (float*)take(ncand * sizeof(float));
+        r.cand_idx = (int*)take(ncand * sizeof(int));
+        r.topk_bytes = topk_ws_bytes(qb, cdiv(G, RK_BN) * (i64)k, k);
+    } else {
+        r.S = (float*)take(need_S ? (size_t)qb * G * sizeof(float) : 0);
+        r.topk_bytes = k > 0 ? topk_ws_bytes(qb, G, k) : 0;
+    }
     r.topk = take(r.topk_bytes);
     r.total = off + 256;
     return r;
 }
 
-template <int MT, int BK, bool VEC>
-static int launch_gemm(const float* qn, const float* gal, const float* ginv, float* S, int Q, i64 G, int D,
-                       hipStream_t st) {
+template <int MT, int BK, bool VEC, int FK>
+static int launch_gemm(const float* qn, const float* gal, const float* ginv, float* S, int Q, i64 G, int D, int k,
+                       float* cand_val, int* cand_idx, hipStream_t st) {
     constexpr int BM = 64 * MT;
-    const size_t lds = (size_t)2 * (BM + RK_BN) * (BK + 4) * sizeof(float);
-    static bool attr_done = false;  // per instantiation
-    if (!attr_done) {
-        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_cos_gemm<MT, BK, VEC>,
+    const size_t stage = (size_t)2 * (BM + RK_BN) * (BK + 4) * sizeof(float);
+    const size_t tile = FK > 0 ? (size_t)64 * (RK_BN + 4) * sizeof(float) : 0;   // fused selection: 64 rows of the score tile at a time
+    const size_t lds = stage > tile ? stage : tile;
+    static bool attr_done[64] = {false};  // per instantiation and device
+    int dev = 0;
+    MI355_CHECK_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_cos_gemm<MT, BK, VEC, FK>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        attr_done[dev] = true;
     }
     dim3 grid((unsigned)cdiv(G, RK_BN), (unsigned)cdiv(Q, BM));
-    hipLaunchKernelGGL((k_cos_gemm<MT, BK, VEC>), grid, dim3(256), lds, st, qn, gal, ginv, S, Q, G, D);
+    hipLaunchKernelGGL((k_cos_gemm<MT, BK, VEC, FK>), grid, dim3(256), lds, st, qn, gal, ginv, S, Q, G, D, k, cand_val,
+                       cand_idx);
     MI355_LAUNCH_CHECK();
     return OK;
 }
 
+template <int MT, int BK, bool VEC>
+static int launch_gemm_fk(const float* qn, const float* gal, const float* ginv, float* S, int Q, i64 G, int D, int k,
+                          float* cand_val, int* cand_idx, hipStream_t st) {
+    if (!cand_val) return launch_gemm<MT, BK, VEC, 0>(qn, gal, ginv, S, Q, G, D, 0, nullptr, nullptr, st);
+    if (k <= 1) return launch_gemm<MT, BK, VEC, 1>(qn, gal, ginv, S, Q, G, D, k, cand_val, cand_idx, st);
+    if (k <= 2) return launch_gemm<MT, BK, VEC, 2>(qn, gal, ginv, S, Q, G, D, k, cand_val, cand_idx, st);
+    if (k <= 4) return launch_gemm<MT, BK, VEC, 4>(qn, gal, ginv, S, Q, G, D, k, cand_val, cand_idx, st);
+    return launch_gemm<MT, BK, VEC, 8>(qn, gal, ginv, S, Q, G, D, k, cand_val, cand_idx, st);
+}
+
+// S != nullptr: score slab.  cand_val / cand_idx != nullptr: fused per-tile top-k lists [Q][cdiv(G,128)][k] (Q > 4 only).
 static int cos_gemm(const float* qn, const float* gal, const float* ginv, float* S, i64 Q, i64 G, int D,
-                    hipStream_t st) {
+                    hipStream_t st, int k = 0, float* cand_val = nullptr, int* cand_idx = nullptr) {
     const bool vec = vec_ok(qn, D) && vec_ok(gal, D);
     const int q = (int)Q;
-    if (Q <= 4 && (size_t)Q * D * sizeof(float) <= 60 * 1024) {
+    if (!cand_val && Q <= 4 && (size_t)Q * D * sizeof(float) <= 60 * 1024) {
         const size_t lds = (size_t)Q * D * sizeof(float);
         const unsigned blocks = (unsigned)(cdiv(G, 4) < 4096 ? cdiv(G, 4) : 4096);
 #define GEMV_LAUNCH(NQ) hipLaunchKernelGGL((k_cos_gemv<NQ>), dim3(blocks), dim3(256), lds, st, qn, gal, ginv, S, G, D, (int)vec)
@@ -622,10 +777,13 @@ static int cos_gemm(const float* qn, const float* gal, const float* ginv, float*
     }
     // Tile choice, measured on MI355X (tools/bench_rank.py, D = 1536): the exact-fp32 MFMA loop plateaus at 95-110 TFLOP/s
     // for every tile shape, so what differs is the partial last round of tiles.  128-query tiles with BK = 16 keep two
-    // workgroups (41 KB of LDS each) on a CU: a lone workgroup in the last round runs at full speed, which halves the
-    // wave-quantisation loss (Q = 256, G = 100k: 0.83 ms, against 0.95 ms with 256 x 128 tiles, one per CU).
-    if (Q > 64) return vec ? launch_gemm<2, 16, true>(qn, gal, ginv, S, q, G, D, st) : launch_gemm<2, 16, false>(qn, gal, ginv, S, q, G, D, st);
-    return vec ? launch_gemm<1, 32, true>(qn, gal, ginv, S, q, G, D, st) : launch_gemm<1, 32, false>(qn, gal, ginv, S, q, G, D, st);
+    // workgroups on a CU (41 KB of staging, 68 KB with the fused selection's score tile): a lone workgroup in the last
+    // round runs at full speed, which halves the wave-quantisation loss (Q = 256, G = 100k: 0.83 ms, against 0.95 ms
+    // with 256 x 128 tiles, one per CU).
+    if (Q > 64) return vec ? launch_gemm_fk<2, 16, true>(qn, gal, ginv, S, q, G, D, k, cand_val, cand_idx, st)
+                           : launch_gemm_fk<2, 16, false>(qn, gal, ginv, S, q, G, D, k, cand_val, cand_idx, st);
+    return vec ? launch_gemm_fk<1, 32, true>(qn, gal, ginv, S, q, G, D, k, cand_val, cand_idx, st)
+               : launch_gemm_fk<1, 32, false>(qn, gal, ginv, S, q, G, D, k, cand_val, cand_idx, st);
 }
 
 static int check_rank_args(const float* queries, i64 Q, const float* gallery, i64 G, int dim) {
@@ -706,9 +864,19 @@ int mi355_rank_topk(const float* queries, int64_t Q, const float* gallery, int64
         MI355_LAUNCH_CHECK();
     }
     const float* ginv = gallery_is_normalized ? nullptr : w.ginv;
-    const i64 qb = query_block(Q, G);
+    const i64 qb = query_block(Q, G, k);
+    const bool fused = fused_select(Q, G, k);
+    const i64 ntiles = cdiv(G, RK_BN);
     for (i64 qs = 0; qs < Q; qs += qb) {
         const i64 qn = (Q - qs < qb) ? Q - qs : qb;
+        if (fused) {
+            // per-tile top-k straight from the GEMM's accumulators, then a merge of qn x ntiles x k candidates
+            if (int e = cos_gemm(w.qn + qs * dim, gallery, ginv, nullptr, qn, G, dim, st, k, w.cand_val, w.cand_idx)) return e;
+            if (int e = topk_select(w.cand_val, nullptr, qn, ntiles * k, ntiles * k, k, idx_offset, out_val + qs * k,
+                                    (i64*)out_idx + qs * k, w.topk, w.topk_bytes, st, w.cand_idx))
+                return e;
+            continue;
+        }
         if (int e = cos_gemm(w.qn + qs * dim, gallery, ginv, w.S, qn, G, dim, st)) return e;
         if (int e = topk_select(w.S, nullptr, qn, G, G, k, idx_offset, out_val + qs * k, (i64*)out_idx + qs * k,
                                 w.topk, w.topk_bytes, st))
@@ -767,21 +935,21 @@ int mi355_cosine_embedding_loss(const float* x1, const float* x2, int64_t rows, 
 }
 
 int mi355_hit_counts(const int64_t* idx, int64_t Q, int k, const int64_t* query_cls, const int64_t* gallery_cls,
-                     int64_t* counts, void* stream) {
+                     int64_t G, int64_t* counts, void* stream) {
     MI355_REQUIRE(idx && query_cls && gallery_cls && counts, "hit_counts: null pointer");
-    MI355_REQUIRE(Q >= 1 && k >= 1, "hit_counts: bad shape");
+    MI355_REQUIRE(Q >= 1 && k >= 1 && G >= 1, "hit_counts: bad shape");
     hipLaunchKernelGGL(k_hit_counts, dim3((unsigned)cdiv(Q, 256)), dim3(256), 0, (hipStream_t)stream, (const i64*)idx,
-                       (i64)Q, k, (const i64*)query_cls, (const i64*)gallery_cls, (i64*)counts);
+                       (i64)Q, k, (const i64*)query_cls, (const i64*)gallery_cls, (i64)G, (i64*)counts);
     MI355_LAUNCH_CHECK();
     return OK;
 }
 
 int mi355_distinct_class_topn(const int64_t* idx, const float* val, int64_t Q, int k, const int64_t* gallery_cls,
-                              int n, int64_t* out_cls, int64_t* out_idx, float* out_val, void* stream) {
+                              int64_t G, int n, int64_t* out_cls, int64_t* out_idx, float* out_val, void* stream) {
     MI355_REQUIRE(idx && val && gallery_cls && out_cls && out_idx && out_val, "distinct_class_topn: null pointer");
-    MI355_REQUIRE(Q >= 1 && k >= 1 && n >= 1 && n <= 8, "distinct_class_topn: bad shape (n must be 1..8)");
+    MI355_REQUIRE(Q >= 1 && k >= 1 && G >= 1 && n >= 1 && n <= 8, "distinct_class_topn: bad shape (n must be 1..8)");
     hipLaunchKernelGGL(k_distinct_topn, dim3((unsigned)cdiv(Q, 128)), dim3(128), 0, (hipStream_t)stream,
-                       (const i64*)idx, val, (i64)Q, k, (const i64*)gallery_cls, n, (i64*)out_cls, (i64*)out_idx,
+                       (const i64*)idx, val, (i64)Q, k, (const i64*)gallery_cls, (i64)G, n, (i64*)out_cls, (i64*)out_idx,
                        out_val);
     MI355_LAUNCH_CHECK();
     return OK;

@@ -265,7 +265,7 @@ def hit_counts(idx: torch.Tensor, query_cls: torch.Tensor, gallery_cls: torch.Te
     if idx.shape[0]:
         with torch.cuda.device(idx.device):
             check(lib().mi355_hit_counts(idx.data_ptr(), idx.shape[0], idx.shape[1], qc.data_ptr(), gc.data_ptr(),
-                                         counts.data_ptr(), stream_ptr(idx.device)))
+                                         gc.numel(), counts.data_ptr(), stream_ptr(idx.device)))
     return counts
 
 
@@ -281,7 +281,7 @@ def distinct_class_topn(idx: torch.Tensor, val: torch.Tensor, gallery_cls: torch
     ov = torch.empty((Q, n), dtype=torch.float32, device=idx.device)
     if Q:
         with torch.cuda.device(idx.device):
-            check(lib().mi355_distinct_class_topn(idx.data_ptr(), val.data_ptr(), Q, k, gc.data_ptr(), n,
+            check(lib().mi355_distinct_class_topn(idx.data_ptr(), val.data_ptr(), Q, k, gc.data_ptr(), gc.numel(), n,
                                                   oc.data_ptr(), oi.data_ptr(), ov.data_ptr(),
                                                   stream_ptr(idx.device)))
     return oc, oi, ov

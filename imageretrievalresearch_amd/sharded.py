@@ -7,11 +7,13 @@ the one place the hot path has a real exchange step:
   1. every rank embeds its own images -> its gallery shard is *born* local, rows
      ``[offset[r], offset[r+1])`` of the global gallery; no collective during embedding
   2. queries are replicated with one all-gather of (Q_local, D) fp32 (1.5 MB at Q=256)
-  3. each rank runs the fused cosine + top-k over its shard -> (Q, k) {score, GLOBAL index}
-  4. one all-gather of the candidates (Q*k*12 bytes per rank: KBs, so latency- not link-bound; RCCL picks
+  3. each rank runs cosine + top-k over its shard (k <= 8: selected inside the GEMM epilogue, no score slab)
+     -> (Q, k) {f32 score, i32 LOCAL index}
+  4. ONE all-gather of the packed candidates (Q*k*8 bytes per rank: KBs, so latency- not link-bound; RCCL picks
      a direct one-hop exchange at this size, a ring would be 7 serial xGMI hops for nothing)
-  5. every rank merges world*k candidates per query with the same ordering rule
-     (higher score, then LOWER global index) -> identical to the single-GPU result, bit for bit.
+  5. every rank adds the shard offsets (a device tensor, no host sync) and merges world*k candidates per query
+     with the same ordering rule (higher score, then LOWER global index) -> identical to the single-GPU result,
+     bit for bit.
 
 world_size == 1 never touches torch.distributed.
 """
@@ -55,36 +57,40 @@ class ShardedGallery:
         self.device = local_rows.device
         self.local = self.ops.normalize(local_rows.float().contiguous()) if local_rows.shape[0] else local_rows.float()
         self.labels = labels
-        n = torch.tensor([local_rows.shape[0]], dtype=torch.int64, device=self.device)
         if self.world > 1:
-            counts = [torch.zeros_like(n) for _ in range(self.world)]
-            dist.all_gather(counts, n, group=group)
-            counts = [int(c.item()) for c in counts]
+            n = torch.tensor([local_rows.shape[0]], dtype=torch.int64, device=self.device)
+            allc = torch.empty(self.world, dtype=torch.int64, device=self.device)
+            dist.all_gather_into_tensor(allc, n, group=group)
+            counts = allc.cpu().tolist()                     # ONE device->host copy for the whole table
         else:
-            counts = [int(n.item())]
+            counts = [int(local_rows.shape[0])]
+        if any(c >= 2 ** 31 - 128 for c in counts):
+            raise MI355Error("a gallery shard must have fewer than 2^31 rows (candidates carry int32 local indices)")
         self.counts = counts
         self.offsets = [0]
         for c in counts:
             self.offsets.append(self.offsets[-1] + c)
         self.total_rows = self.offsets[-1]
+        self._offsets_dev = torch.tensor(self.offsets[:-1], dtype=torch.int64, device=self.device).view(self.world, 1, 1)
 
     @property
     def offset(self) -> int:
         return self.offsets[self.rank]
 
     def _local_candidates(self, queries, k):
+        """(Q, k, 2) int32: [..., 0] = the f32 score's bits, [..., 1] = LOCAL row index (-1 = no candidate)."""
         Q = queries.shape[0]
         rows = self.local.shape[0]
         kk = min(k, rows)
+        packed = torch.empty((Q, k, 2), dtype=torch.int32, device=self.device)
         if kk > 0:
-            v, i = self.ops.local_topk(queries, self.local, kk, self.offset)
-        else:
-            v = torch.empty((Q, 0), dtype=torch.float32, device=self.device)
-            i = torch.empty((Q, 0), dtype=torch.int64, device=self.device)
+            v, i = self.ops.local_topk(queries, self.local, kk, 0)
+            packed[:, :kk, 0] = v.contiguous().view(torch.int32)
+            packed[:, :kk, 1] = i.to(torch.int32)
         if kk < k:  # short (or empty) shard: pad so every rank contributes exactly k slots
-            v = torch.cat([v, torch.full((Q, k - kk), float("-inf"), dtype=torch.float32, device=self.device)], 1)
-            i = torch.cat([i, torch.full((Q, k - kk), _PAD_IDX, dtype=torch.int64, device=self.device)], 1)
-        return v.contiguous(), i.contiguous()
+            packed[:, kk:, 0] = torch.tensor(float("-inf"), dtype=torch.float32).view(torch.int32).item()
+            packed[:, kk:, 1] = -1
+        return packed
 
     def search(self, queries_local: torch.Tensor, k: int):
         """Top-k of every rank's queries against the WHOLE gallery.
@@ -100,14 +106,14 @@ class ShardedGallery:
         Ql = q.shape[0]
         allq = torch.empty((self.world * Ql, self.dim), dtype=torch.float32, device=self.device)
         dist.all_gather_into_tensor(allq, q, group=self.group)
-        v, i = self._local_candidates(allq, k)
+        packed = self._local_candidates(allq, k)
         Q = allq.shape[0]
-        gv = torch.empty((self.world * Q, k), dtype=torch.float32, device=self.device)   # rank-major concat
-        gi = torch.empty((self.world * Q, k), dtype=torch.int64, device=self.device)
-        dist.all_gather_into_tensor(gv, v, group=self.group)
-        dist.all_gather_into_tensor(gi, i, group=self.group)
-        gv = gv.view(self.world, Q, k)
-        gi = gi.view(self.world, Q, k)
+        allp = torch.empty((self.world * Q, k, 2), dtype=torch.int32, device=self.device)   # rank-major concat
+        dist.all_gather_into_tensor(allp, packed, group=self.group)                             # the ONE candidate exchange
+        allp = allp.view(self.world, Q, k, 2)
+        gv = allp[..., 0].contiguous().view(torch.float32)
+        li = allp[..., 1].to(torch.int64)
+        gi = torch.where(li >= 0, li + self._offsets_dev, torch.full_like(li, _PAD_IDX))      # rank offset added here
         cv = gv.permute(1, 0, 2).reshape(Q, self.world * k).contiguous()
         ci = gi.permute(1, 0, 2).reshape(Q, self.world * k).contiguous()
         return self.ops.merge(cv, ci, k)

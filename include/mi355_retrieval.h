@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MI355_ABI_VERSION 1
+#define MI355_ABI_VERSION 2
 
 /* ------------------------------------------------------------------ library / errors */
 int mi355_abi_version(void);
@@ -42,7 +42,8 @@ int mi355_synth_fill(float* out, int64_t n, uint64_t seed, int64_t offset, int k
  * Replaces torch.nn.CosineSimilarity(dim=1, eps=1e-6) + torch.topk at
  *   train/train.py:250-251, :345-356 ; inference/inference.py:226-242 ; notebook raw :231-251.
  * Semantics (pinned): score[q][g] = sum_d (Q[q][d]/max(|Q[q]|,eps)) * (G[g][d]/max(|G[g]|,eps)),
- * fp32 throughout (exact-f32 MFMA); top-k sorted by descending score, ties -> lower index first. */
+ * fp32 throughout (exact-f32 MFMA); top-k sorted by descending score, ties -> lower index first; a NaN score orders as
+ * the largest value (as torch.topk does), two NaNs tie. */
 
 /* out[r][:] = in[r][:] / max(||in[r]||_2, eps); in == out allowed.  rows x dim fp32 row-major. */
 int mi355_l2_normalize_rows(const float* in, float* out, int64_t rows, int dim, float eps, void* stream);
@@ -97,14 +98,16 @@ int mi355_cosine_embedding_loss(const float* x1, const float* x2, int64_t rows, 
 
 /* Hit counting, train/train.py:252-255: counts[0] += #queries whose class equals the class of
  * their top-1 result, counts[1] += #queries whose class is among their top-min(3,k).
- * idx [Q][k] int64 into gallery_cls; counts int64[2] must be zeroed by the caller. */
+ * idx [Q][k] int64 into gallery_cls [G]; counts int64[2] must be zeroed by the caller.  An index outside [0, G)
+ * (the pad entry of a list with fewer than k real candidates) counts as a miss. */
 int mi355_hit_counts(const int64_t* idx, int64_t Q, int k, const int64_t* query_cls,
-                     const int64_t* gallery_cls, int64_t* counts, void* stream);
+                     const int64_t* gallery_cls, int64_t G, int64_t* counts, void* stream);
 
 /* Notebook variant, inference/training_analysis.ipynb raw :240-251: walk each ranked list and keep
- * the first n (<= 8) DISTINCT classes.  out_cls/out_idx [Q][n] int64 (-1 padded), out_val [Q][n]. */
+ * the first n (<= 8) DISTINCT classes.  out_cls/out_idx [Q][n] int64 (-1 padded), out_val [Q][n].
+ * gallery_cls [G]; indices outside [0, G) are skipped. */
 int mi355_distinct_class_topn(const int64_t* idx, const float* val, int64_t Q, int k,
-                              const int64_t* gallery_cls, int n, int64_t* out_cls, int64_t* out_idx,
+                              const int64_t* gallery_cls, int64_t G, int n, int64_t* out_cls, int64_t* out_idx,
                               float* out_val, void* stream);
 
 /* ------------------------------------------------------------------ backbone models
@@ -154,6 +157,13 @@ int mi355_model_forward(mi355_model_t m, const float* x, int B, int H, int W, fl
 int mi355_model_enable_taps(mi355_model_t m, int enable);
 int mi355_model_read_tap(mi355_model_t m, const char* tap_name, float* out, int64_t out_numel,
                          int64_t shape[4], void* stream);
+
+/* Parity tool: run ONLY the layers behind tap `from_tap` up to and including the one that records tap `to_tap` on an
+ * activation supplied by the caller: x [B][C][h][w] fp32 NCHW on the device (rounded to bf16 on the way in; feed it the
+ * oracle's bf16-rounded tap of the previous layer).  Taps are recorded as in a normal forward (enable them first), so a
+ * layer is compared with the oracle on the ORACLE's input and errors do not compound through the network. */
+int mi355_model_run_between_taps(mi355_model_t m, const char* from_tap, const char* to_tap, const float* x, int B,
+                                 int C, int h, int w, void* stream);
 
 /* Algorithmic HBM bytes of one forward at batch B (layer-granular model) and the
  * MACs; used by bench.py's roofline. */

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_loads_and_reports_version_without_gpu():
     L = _lib.lib()
-    assert L.mi355_abi_version() == 1
+    assert L.mi355_abi_version() == 2
     assert L.mi355_device_count() >= 0
     assert isinstance(L.mi355_last_error(), bytes)
 
@@ -31,7 +31,10 @@ def test_argument_errors_do_not_need_a_gpu():
     # bad arguments are rejected before any HIP call, with a message
     assert L.mi355_rank_topk(None, 1, None, 1, 8, 0, 1, 1e-6, 0, None, None, None, 0, None) != 0
     assert b"null" in L.mi355_last_error()
-    assert L.mi355_rank_workspace_bytes(256, 100000, 1536, 3) > 256 * 100000 * 4
+    # k <= 8 selects inside the GEMM epilogue: no Q x G score slab in the workspace (candidates are Q * ceil(G/128) * k * 8 B)
+    assert L.mi355_rank_workspace_bytes(256, 100000, 1536, 3) < 16 * 2**20
+    assert L.mi355_rank_workspace_bytes(2048, 125000, 1536, 3) < 64 * 2**20      # the 8-GPU shape (all-gathered queries)
+    assert L.mi355_rank_workspace_bytes(256, 100000, 1536, 150) > 256 * 100000 * 4   # k > 8 keeps the slab path
     assert L.mi355_rank_workspace_bytes(0, 10, 8, 1) == 0
 
 

@@ -38,3 +38,21 @@ def test_plain_checkpoint_replaces_classifier(tmp_path):
                               from_pytorch_lightning=False)
     assert isinstance(model.classifier, torch.nn.Linear) and model.classifier.out_features == 125
     assert M.strip_lightning_prefix({"model.model.x": 1}) == {"x": 1}      # str.replace removes every occurrence
+
+
+def test_reload_through_a_parent_module_requests_a_repack():
+    """nn.Module.load_state_dict on a PARENT (the reference's Sequential(conv_input, model) wrapper, or a
+    LightningModule holding self.model) never calls the child's load_state_dict override; the packed HIP weights must
+    still be invalidated - in eval mode too - and so must an in-place parameter write."""
+    model = M.create_model("efficientnet_b3a", num_classes=0).eval()
+    model.__dict__["_dirty"] = False                      # as if packed
+    model.__dict__["_sig"] = model._signature()
+    wrapped = M.models.with_conv_input(model)
+    wrapped.load_state_dict({k: v.clone() for k, v in wrapped.state_dict().items()})
+    assert model._dirty
+    model.__dict__["_dirty"] = False
+    model.__dict__["_sig_tensors"] = None
+    model.__dict__["_sig"] = model._signature()
+    with torch.no_grad():
+        model.conv_stem.weight.mul_(2.0)
+    assert model._sig != model._signature()

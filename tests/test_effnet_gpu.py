@@ -166,3 +166,116 @@ def test_odd_input_sizes_and_errors(setup):
         model(torch.zeros(1, 1, 224, 224, device=DEV))
     with pytest.raises(M.MI355Error):
         M.create_model("efficientnet_b3a", pretrained=True)
+
+
+def test_reload_in_eval_mode_uses_the_new_weights(setup):
+    """forward, then load new weights through the PARENT wrapper in eval mode, forward again: the
+    second output must be the oracle's for the new weights (a stale pack would reproduce the first)."""
+    sd, _ = setup
+    x = torch.from_numpy(images(13, 2))
+    model = M.create_model("efficientnet_b3a", num_classes=0)
+    wrapped = M.models.with_conv_input(model).to(DEV).eval()
+    w0 = torch.zeros(3, 3, 3, 3)
+    for c in range(3):
+        w0[c, c, 1, 1] = 1.5                               # conv_input ~ identity x 1.5 before its SiLU
+    full = {"0.0.weight": w0}
+    full.update({"1." + k: v for k, v in sd.items() if not k.startswith("classifier.")})
+    wrapped.load_state_dict(full)
+    first = wrapped(x.to(DEV)).cpu()
+    sd2 = effnet.init_state_dict(3)
+    full2 = {"0.0.weight": w0}
+    full2.update({"1." + k: v for k, v in sd2.items() if not k.startswith("classifier.")})
+    wrapped.load_state_dict(full2)                         # parent load, eval mode, after a forward
+    second = wrapped(x.to(DEV)).cpu()
+    pre = torch.nn.functional.silu(torch.nn.functional.conv2d(x, w0, padding=1))
+    want2 = effnet.pool(effnet.forward_features(sd2, pre, sim_bf16=True))
+    assert rel(second, want2) < TOL_EMB_SIM
+    assert rel(first, want2) > 0.1                         # the two weight sets really differ
+    with torch.no_grad():                                  # in-place write in eval mode is picked up too
+        wrapped[1].conv_stem.weight.zero_()
+    third = wrapped(x.to(DEV)).cpu()
+    # a zero stem makes the network blind to its input: both images now embed identically (and not as before)
+    assert torch.equal(third[0], third[1]) and not torch.equal(second[0], second[1]) and not torch.equal(third, second)
+
+
+def test_lightning_checkpoint_to_gpu_forward(setup, tmp_path):
+    """f-2 on the GPU (inference/inference.py:98,113-124): a Lightning-style .ckpt with ``model.1.`` / ``model.0.0``
+    keys -> load_checkpoint(conv_input=True) -> .to(device) -> forward, against the oracle on the conv_input output."""
+    sd, _ = setup
+    w0 = synth.normal(5, (3, 3, 3, 3)).astype(np.float32) * 0.3
+    ck = {"model.1." + k: v for k, v in sd.items()}
+    ck["model.0.0.weight"] = torch.from_numpy(w0)
+    path = tmp_path / "epoch=3-val_loss=0.10-cos_sims=0.90-val_top1=0.80.ckpt"
+    torch.save({"state_dict": ck, "epoch": 3}, path)
+    model = M.load_checkpoint(str(path), "efficientnet_b3a", conv_input=True)
+    assert not model.load_report.missing_keys and not model.load_report.unexpected_keys
+    model = model.to(DEV).eval()
+    x = torch.from_numpy(images(15, 2))
+    got = model(x.to(DEV)).cpu()                           # default 1000-way head kept, as the reference does (:102)
+    pre = torch.nn.functional.silu(torch.nn.functional.conv2d(x, torch.from_numpy(w0), padding=1))
+    want = effnet.forward(sd, pre, sim_bf16=True)
+    assert got.shape == want.shape == (2, 1000)
+    assert rel(got, want) < 1e-2
+
+
+def test_block_kernel_agrees_with_the_unfused_chain(setup):
+    """The whole-block kernel (14x14 / 7x7 stages) against expand -> depthwise -> SE -> gated projection as separate
+    kernels on the same weights: same rounding points, different summation orders - the first fused block may differ
+    from the chain only by a few bf16 roundings, and nothing may depend on the position in the batch."""
+    sd, model = setup
+    x = torch.from_numpy(images(17, 3)).to(DEV)
+    names = ["blocks.3.0", "blocks.3.1", "blocks.4.0", "blocks.5.0", "blocks.6.1", "head"]
+    taps = {}
+    for opt in (0, 1):
+        model.set_option("fuse_block", opt)
+        model.enable_taps(True)
+        model.forward_features(x)
+        taps[opt] = {n: model.read_tap(n).cpu() for n in names}
+        model.enable_taps(False)
+    model.set_option("fuse_block", 1)
+    assert torch.equal(taps[0]["blocks.3.0"], taps[1]["blocks.3.0"])      # last block before the fused stages
+    first = rel(taps[1]["blocks.3.1"], taps[0]["blocks.3.1"])
+    assert first < 2.5e-3, first                                           # < 1 bf16 ulp relative L2
+    for n in names[2:]:
+        assert rel(taps[1][n], taps[0][n]) < 1.2e-2, n
+    xx = x[:1].repeat(5, 1, 1, 1).contiguous()                            # same image at five batch positions
+    out = model.forward_features(xx)
+    for i in range(1, 5):
+        assert torch.equal(out[0], out[i]), i
+
+
+TOL_BLOCK_ISOLATED = 1.5e-3   # measured <= 6e-4: a fraction of one bf16 ulp (2^-8 = 3.9e-3) of relative L2 for ONE block fed the oracle's own input
+
+
+@pytest.mark.parametrize("B", [2, 256])
+def test_each_block_on_the_oracles_own_input(setup, B):
+    """Every layer group between two taps (stem -> block -> ... -> head) is run ALONE on the oracle's bf16-rounded
+    activation of the previous tap (mi355_model_run_between_taps), so an error cannot hide behind the compounding
+    tolerance of the whole-network test.  B = 256 repeats the two oracle images 128 times: that is the M (= 256*h*w
+    rows) at which the executor picks its B=256 kernels (DMA GEMM, streaming GEMM, band / whole-block fusion), and
+    every repeat must be bit-identical to the first."""
+    sd, model = setup
+    x = torch.from_numpy(images(19, 2))
+    taps = {}
+    want_head = effnet.forward_features(sd, x, sim_bf16=True, taps=taps)
+    taps["head"] = want_head
+    order = list(taps.keys())
+    assert order[0] == "stem" and order[-1] == "head" and len(order) == 28
+    model.enable_taps(True)
+    worst = ("", 0.0)
+    for prev, cur in zip(order[:-1], order[1:]):
+        src = taps[prev].to(DEV)
+        if B > 2:
+            src = src.repeat(B // 2, 1, 1, 1).contiguous()
+        model.run_between_taps(prev, cur, src)
+        got = model.read_tap(cur)
+        del src
+        if B > 2:
+            g = got.view(B // 2, 2, *got.shape[1:])
+            assert torch.equal(g[0], g[1]) and torch.equal(g[0], g[-1]), f"{cur}: result depends on the batch position"
+            got = g[0]
+        e = rel(got.cpu(), taps[cur])
+        worst = max(worst, (cur, e), key=lambda p: p[1])
+        assert e < TOL_BLOCK_ISOLATED, f"{prev} -> {cur} at B={B}: rel L2 {e:.3e}"
+    model.enable_taps(False)
+    print(f"B={B}: worst isolated block {worst}")

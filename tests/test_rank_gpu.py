@@ -255,3 +255,50 @@ def test_query_blocking_over_a_3m_row_gallery():
         if np.min(s[order][:-1] - s[order][1:]) > 1e-5:
             assert i[p].cpu().tolist() == order[:k].tolist()
         np.testing.assert_allclose(v[p].cpu().numpy(), s[order[:k]], atol=SCORE_TOL)
+
+
+@pytest.mark.parametrize("Qn,k", [(16, 3), (130, 3), (3, 3), (16, 150)])
+def test_nan_scores_order_as_largest_like_torch(Qn, k):
+    """torch.topk treats NaN as the largest value: a NaN embedding (bf16 overflow upstream) must come back with an
+    in-range index, never as a pad entry that the class gathers would read out of bounds (fused-select, GEMV and
+    slab + bitonic paths: Q > 4 / Q <= 4 / k > 8)."""
+    Gn, d = 1000, 64
+    Q = synth.normal(11, (Qn, d)).astype(np.float32)
+    G = synth.normal(12, (Gn, d)).astype(np.float32)
+    G[37, 5] = np.nan                      # one gallery row with a NaN -> its score is NaN for every query
+    Q[1, :] = np.nan                       # one all-NaN query -> every score of that row is NaN
+    v, i = M.cosine_topk(dev(Q), dev(G), k)
+    v, i = v.cpu().numpy(), i.cpu().numpy()
+    assert i.min() >= 0 and i.max() < Gn, "a pad index leaked out"
+    sim = torch.nn.CosineSimilarity(dim=1, eps=1e-6)
+    for q in range(Qn):
+        want_v, want_i = torch.topk(sim(torch.from_numpy(Q[q][None]), torch.from_numpy(G)), k)
+        if q == 1:
+            assert np.isnan(v[q]).all()
+            np.testing.assert_array_equal(i[q], np.arange(k))          # all tied (NaN): lower index first
+            continue
+        assert np.isnan(v[q, 0]) and i[q, 0] == 37 and bool(torch.isnan(want_v[0])) and int(want_i[0]) == 37
+        np.testing.assert_allclose(v[q, 1:], want_v[1:].numpy(), atol=SCORE_TOL)
+        np.testing.assert_array_equal(i[q, 1:], want_i[1:].numpy())
+    # hit counting on these lists stays in bounds; an explicit pad index counts as a miss
+    gcls = torch.arange(Gn) % 7
+    counts = M.hit_counts(torch.from_numpy(i).to(DEV), torch.zeros(Qn, dtype=torch.int64), gcls)
+    assert int(counts[1]) >= int(counts[0]) >= 0
+    pad = torch.full((4, 3), np.iinfo(np.int64).max, dtype=torch.int64)
+    assert M.hit_counts(pad.to(DEV), torch.zeros(4, dtype=torch.int64), gcls).tolist() == [0, 0]
+    oc, oi, ov = M.distinct_class_topn(pad.to(DEV), torch.zeros(4, 3).to(DEV), gcls.to(DEV), 3)
+    assert (oc.cpu() == -1).all()
+
+
+def test_fused_select_matches_slab_path_bit_for_bit():
+    """k <= 8 is selected inside the GEMM epilogue (no score slab); it must return exactly what selecting from the
+    explicit score matrix returns (same tie rule), including ragged tiles and ties across column tiles."""
+    Qn, Gn, d = 200, 5000, 96
+    Q = synth.normal(21, (Qn, d)).astype(np.float32)
+    G = synth.normal(22, (Gn, d)).astype(np.float32)
+    G[130] = G[3]; G[4999] = G[3]; G[2000] = G[1999]          # exact duplicates in different column tiles
+    for k in (1, 3, 8):
+        v, i = M.cosine_topk(dev(Q), dev(G), k)
+        S = M.cosine_scores(dev(Q), dev(G))
+        v2, i2 = M.topk(S, k)
+        assert torch.equal(v, v2) and torch.equal(i, i2), k

@@ -66,7 +66,8 @@ def _worker(rank, world, port, bounds, k, out):
         torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,bounds,k", [(2, [0, 150, 300], 3), (3, [0, 100, 101, 260], 5), (2, [0, 2, 50], 4)])
+@pytest.mark.parametrize("world,bounds,k", [(2, [0, 150, 300], 3), (3, [0, 100, 101, 260], 5), (2, [0, 2, 50], 4),
+                                            (8, [0, 33, 33, 90, 91, 160, 200, 201, 260], 3)])   # 8 ranks, ragged, one empty shard
 def test_sharded_equals_unsharded(world, bounds, k):
     port = _free_port()
     mgr = mp.get_context("spawn").Manager()
