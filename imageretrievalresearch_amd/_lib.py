@@ -46,6 +46,8 @@ PROTOTYPES = {
     "mi355_model_pack": (C.c_int, [vp, vp]),
     "mi355_model_forward_features": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "mi355_model_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "mi355_model_forward_u8": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                         vp, C.c_int, vp, vp, vp]),
     "mi355_model_enable_taps": (C.c_int, [vp, C.c_int]),
     "mi355_model_read_tap": (C.c_int, [vp, C.c_char_p, vp, C.c_int64, C.POINTER(C.c_int64), vp]),
     "mi355_model_run_between_taps": (C.c_int, [vp, C.c_char_p, C.c_char_p, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
@@ -58,6 +60,7 @@ PROTOTYPES = {
     "mi355_model_profile_ops": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
                                           C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     "mi355_model_block_stamps": (C.c_int, [vp, C.POINTER(C.c_double), C.c_int]),
+    "mi355_pool_linear": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp]),
     "mi355_gemm_bf16": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "mi355_square_pad_normalize": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp]),
     "mi355_conv_input_silu": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),

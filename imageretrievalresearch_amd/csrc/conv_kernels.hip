@@ -81,6 +81,116 @@ int launch_stem(const float* x, const float* w, const float* bias, bf16_t* out, 
 }
 
 // =====================================================================================
+// Fused input: uint8 HWC image -> SquarePad(fill) -> /255 -> Normalize -> [conv_input 3x3 + SiLU] -> stem 3x3/s2 ->
+// NHWC bf16, one kernel, no fp32 NCHW batch in HBM (SURVEY §8f f-1 + §8a a5; utils/square_pad.py:20-36,
+// inference/inference.py:48-52,101-105).  Same thread = output pixel structure and the SAME fp32 operation order as
+// k_square_pad_normalize -> k_conv_input_silu -> k_stem, so its output is bit-identical to that chain.
+// =====================================================================================
+struct StemU8Args {
+    const unsigned char* img;   // [B][h][w][3]
+    int h, w, S, hp, vp, fill;  // S = max(h, w); hp / vp = left / top padding
+    float mean[3], stdv[3];
+    const float* cw;            // conv_input weights [3][3][3][3] (co, ci, ky, kx) on the device, or null
+};
+
+template <bool CONV_INPUT>
+__global__ __launch_bounds__(256) void k_stem_u8(const StemU8Args a, const float* __restrict__ w,
+                                                 const float* __restrict__ bias, bf16_t* __restrict__ out, int Ho, int Wo,
+                                                 int Cout, int act) {
+    __shared__ float scw[81];
+    if (CONV_INPUT) {
+        if (threadIdx.x < 81) scw[threadIdx.x] = a.cw[threadIdx.x];
+        __syncthreads();
+    }
+    const int b = blockIdx.z;
+    const int ox = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int oy = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (ox >= Wo || oy >= Ho) return;
+    const unsigned char* ib = a.img + (size_t)b * a.h * a.w * 3;
+    // the model input at (y, x, c): 0 outside the S x S square (the convolutions' zero padding), the normalised fill
+    // colour in the SquarePad border, the normalised pixel inside the image - one rounding per fp32 op, as torch does
+    auto pre = [&](int y, int x, int c) -> float {
+        if (y < 0 || y >= a.S || x < 0 || x >= a.S) return 0.f;
+        const int iy = y - a.vp, ix = x - a.hp;
+        int v = a.fill;
+        if (iy >= 0 && iy < a.h && ix >= 0 && ix < a.w) v = ib[((size_t)iy * a.w + ix) * 3 + c];
+        return __fdiv_rn(__fsub_rn(__fdiv_rn((float)v, 255.0f), a.mean[c]), a.stdv[c]);
+    };
+    float p[27];
+    if (!CONV_INPUT) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) p[(ky * 3 + kx) * 3 + ci] = pre(oy * 2 - 1 + ky, ox * 2 - 1 + kx, ci);
+    } else {
+        // 5x5 window of the pre-processed image around the stem's 3x3 taps, then conv_input + SiLU at the nine taps
+        float q[5][5][3];
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 5; ++dx)
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) q[dy][dx][ci] = pre(oy * 2 - 2 + dy, ox * 2 - 2 + dx, ci);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int y = oy * 2 - 1 + ky, x = ox * 2 - 1 + kx;
+                float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci)            // same (ci, ky, kx) order as k_conv_input_silu
+#pragma unroll
+                    for (int ky2 = 0; ky2 < 3; ++ky2)
+#pragma unroll
+                        for (int kx2 = 0; kx2 < 3; ++kx2) {
+                            const float v = q[ky + ky2][kx + kx2][ci];
+#pragma unroll
+                            for (int co = 0; co < 3; ++co) acc[co] += v * scw[((co * 3 + ci) * 3 + ky2) * 3 + kx2];
+                        }
+                const bool in = y >= 0 && y < a.S && x >= 0 && x < a.S;   // outside: the stem's zero padding
+#pragma unroll
+                for (int co = 0; co < 3; ++co) p[(ky * 3 + kx) * 3 + co] = in ? silu_f(acc[co]) : 0.f;
+            }
+    }
+    bf16_t* o = out + (((size_t)b * Ho + oy) * Wo + ox) * Cout;
+    for (int c0 = 0; c0 < Cout; c0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = bias[c0 + j];
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(&w[t * Cout + c0]);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(&w[t * Cout + c0 + 4]);
+            acc[0] += p[t] * w0.x; acc[1] += p[t] * w0.y; acc[2] += p[t] * w0.z; acc[3] += p[t] * w0.w;
+            acc[4] += p[t] * w1.x; acc[5] += p[t] * w1.y; acc[6] += p[t] * w1.z; acc[7] += p[t] * w1.w;
+        }
+        MI355_ACT_DISPATCH(act, {
+_Pragma("unroll")
+            for (int j = 0; j < 8; ++j) acc[j] = act_c<ACT>(acc[j]);
+        })
+        *reinterpret_cast<u32x4*>(o + c0) = pack8(acc);
+    }
+}
+
+int launch_stem_u8(const unsigned char* img, int h, int w, int fill, const float* mean, const float* stdv,
+                   const float* conv_w, const float* sw, const float* bias, bf16_t* out, int B, int Cout, int act,
+                   hipStream_t st) {
+    MI355_REQUIRE(Cout % 8 == 0 && Cout <= 256, "stem: Cout=%d must be a multiple of 8 and <= 256", Cout);
+    StemU8Args a{};
+    a.img = img; a.h = h; a.w = w; a.S = h > w ? h : w; a.hp = (a.S - w) / 2; a.vp = (a.S - h) / 2; a.fill = fill;
+    for (int c = 0; c < 3; ++c) { a.mean[c] = mean[c]; a.stdv[c] = stdv[c]; }
+    a.cw = conv_w;
+    const int Ho = (a.S + 2 - 3) / 2 + 1, Wo = Ho;
+    dim3 grid(cdiv(Wo, 32), cdiv(Ho, 8), B);
+    if (conv_w) hipLaunchKernelGGL((k_stem_u8<true>), grid, dim3(256), 0, st, a, sw, bias, out, Ho, Wo, Cout, act);
+    else hipLaunchKernelGGL((k_stem_u8<false>), grid, dim3(256), 0, st, a, sw, bias, out, Ho, Wo, Cout, act);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
+// =====================================================================================
 // depthwise k x k.  One thread = 8 channels x PX consecutive output pixels of one row.
 // Threads are laid out channel-group fastest, so a wave reads/writes contiguous NHWC bytes.
 // SE squeeze: each thread sums its (un-rounded, activated) outputs; threads of a block that share a
@@ -496,6 +606,42 @@ int launch_gap(const bf16_t* in, float* pooled, bf16_t* pooled_bf16, int B, int 
     MI355_REQUIRE(C % 8 == 0, "gap: C=%d must be a multiple of 8", C);
     const long total = (long)B * (C / 8);
     hipLaunchKernelGGL(k_gap, dim3(cdiv(total, 256)), dim3(256), 0, st, in, pooled, pooled_bf16, HW, C, total);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
+// timm ClassifierHead on the un-pooled map (train/train.py:194-195: fm = forward_features(x); lbl = model.head(fm)):
+// fm [B][C][HW] fp32 NCHW -> global average pool (fp32, same summation order as k_gap) -> bf16 -> Linear with bf16
+// weights and fp32 accumulation (the rounding points of the in-model classifier GEMM).  One workgroup per image.
+__global__ __launch_bounds__(256) void k_pool_linear(const float* __restrict__ fm, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ out,
+                                                     float* __restrict__ pooled_out, int C, int HW, int N) {
+    extern __shared__ float pl[];   // [C] pooled, bf16-rounded values
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* f = fm + (size_t)b * C * HW;
+    const float inv = 1.0f / (float)HW;
+    for (int c = tid; c < C; c += 256) {
+        float a = 0.f;
+        for (int i = 0; i < HW; ++i) a += f[(size_t)c * HW + i];
+        a *= inv;
+        if (pooled_out) pooled_out[(size_t)b * C + c] = a;
+        pl[c] = bf2f(f2bf(a));
+    }
+    __syncthreads();
+    if (w == nullptr) return;
+    for (int n = wave; n < N; n += 4) {
+        const float* wr = w + (size_t)n * C;
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a += bf2f(f2bf(wr[c])) * pl[c];
+        a = wave_sum(a);
+        if (lane == 0) out[(size_t)b * N + n] = a + (bias ? bias[n] : 0.f);
+    }
+}
+
+int launch_pool_linear(const float* fm, const float* w, const float* bias, float* out, float* pooled_out, int B, int C,
+                       int HW, int N, hipStream_t st) {
+    MI355_REQUIRE((size_t)C * 4 <= 64 * 1024, "pool_linear: C=%d too large", C);
+    hipLaunchKernelGGL(k_pool_linear, dim3(B), dim3(256), (size_t)C * 4, st, fm, w, bias, out, pooled_out, C, HW, N);
     MI355_LAUNCH_CHECK();
     return OK;
 }

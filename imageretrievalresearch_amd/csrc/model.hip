@@ -232,6 +232,10 @@ static int exec_op(ExecCtx& cx, const Op& op) {
     SlotState* S = m->slots;
     switch (op.kind) {
         case OP_STEM:
+            if (cx.x_u8)
+                return launch_stem_u8(cx.x_u8, cx.img_h, cx.img_w, cx.fill, cx.mean, cx.stdv, cx.conv_w,
+                                      (const float*)cx.w(op.w_off), (const float*)cx.w(op.b_off),
+                                      (bf16_t*)cx.slot_ptr(op.out), cx.nb, op.cout, op.act, cx.st);
             return launch_stem(cx.x, (const float*)cx.w(op.w_off), (const float*)cx.w(op.b_off),
                                (bf16_t*)cx.slot_ptr(op.out), cx.nb, cx.H, cx.W, op.cout, op.act, cx.st);
         case OP_GEMM: {
@@ -424,11 +428,18 @@ static int run_backbone(ExecCtx& cx, size_t op_begin = 0, size_t op_end = (size_
     return OK;
 }
 
+struct U8Source {                     // uint8 images in front of the stem (mi355_model_forward_u8)
+    const unsigned char* img = nullptr;
+    int h = 0, w = 0, fill = 255;
+    float mean[3] = {0.f, 0.f, 0.f}, stdv[3] = {1.f, 1.f, 1.f};
+    const float* conv_w = nullptr;
+};
+
 static int forward_impl(mi355_model* m, const float* x, int B, int H, int W, float* out, float* pooled_out,
-                        bool features_only, hipStream_t st) {
+                        bool features_only, hipStream_t st, const U8Source* u8 = nullptr) {
     MI355_REQUIRE(m, "forward: null model");
     MI355_REQUIRE(m->packed, "forward: weights not packed (call mi355_model_pack after set_tensor)");
-    MI355_REQUIRE(x && out, "forward: null input/output pointer");
+    MI355_REQUIRE((x || u8) && out, "forward: null input/output pointer");
     MI355_REQUIRE(B >= 1 && H >= 32 && W >= 32, "forward: bad shape B=%d H=%d W=%d", B, H, W);
     const ModelDef& d = m->def;
     if (d.pools_in_features) MI355_REQUIRE(H == 224 && W == 224, "forward: %s needs 224x224 input", d.arch.c_str());
@@ -461,8 +472,13 @@ static int forward_impl(mi355_model* m, const float* x, int B, int H, int W, flo
             st = m->lane_stream[lane];
             MI355_CHECK_HIP(hipStreamWaitEvent(st, m->lane_fork, 0));
         }
-        ExecCtx cx{m, st, nb, H, W, x + (size_t)b0 * 3 * H * W, b0, B};
+        ExecCtx cx{m, st, nb, H, W, x ? x + (size_t)b0 * 3 * H * W : nullptr, b0, B};
         cx.lane = nl > 1 ? lane : 0;
+        if (u8) {
+            cx.x_u8 = u8->img + (size_t)b0 * u8->h * u8->w * 3;
+            cx.img_h = u8->h; cx.img_w = u8->w; cx.fill = u8->fill; cx.conv_w = u8->conv_w;
+            for (int c = 0; c < 3; ++c) { cx.mean[c] = u8->mean[c]; cx.stdv[c] = u8->stdv[c]; }
+        }
         if (int e = run_backbone(cx)) return e;
         const SlotState& F = m->slots[d.final_slot];
         const int hw = F.h * F.w;
@@ -662,6 +678,22 @@ int mi355_model_run_between_taps(mi355_model_t m, const char* from_tap, const ch
     S[src.out].h = h; S[src.out].w = w; S[src.out].c = src.cout;
     if (int e = launch_nchw_f32_to_nhwc_bf16(x, (bf16_t*)cx.slot_ptr(src.out), B, h * w, C, src.cout, st)) return e;
     return run_backbone(cx, i0 + 1, i1 + 1);
+}
+
+int mi355_model_forward_u8(mi355_model_t m, const unsigned char* images, int B, int h, int w, int fill, const float* mean,
+                           const float* stdv, const float* conv_input_w, int features_only, float* out, float* pooled_out,
+                           void* stream) {
+    MI355_REQUIRE(m && images && mean && stdv && out, "forward_u8: null pointer");
+    MI355_REQUIRE(B >= 1 && h >= 1 && w >= 1 && h <= 16384 && w <= 16384, "forward_u8: bad image size %dx%d", h, w);
+    MI355_REQUIRE(fill >= 0 && fill <= 255, "forward_u8: fill must be a byte value");
+    for (int c = 0; c < 3; ++c) MI355_REQUIRE(stdv[c] != 0.f, "forward_u8: std[%d] is zero", c);
+    MI355_REQUIRE(!m->def.ops.empty() && m->def.ops[0].kind == OP_STEM,
+                  "forward_u8: %s has no 3x3 stem to fuse the pre-processing into", m->def.arch.c_str());
+    U8Source u{};
+    u.img = images; u.h = h; u.w = w; u.fill = fill; u.conv_w = conv_input_w;
+    for (int c = 0; c < 3; ++c) { u.mean[c] = mean[c]; u.stdv[c] = stdv[c]; }
+    const int S = h > w ? h : w;
+    return forward_impl(m, nullptr, B, S, S, out, pooled_out, features_only != 0, (hipStream_t)stream, &u);
 }
 
 int mi355_model_enable_taps(mi355_model_t m, int enable) {
@@ -879,6 +911,14 @@ int mi355_gemm_bf16(const void* A, const void* W, const float* bias, void* out, 
     }
     a.zeros = (const bf16_t*)zero_page;
     return launch_gemm_bf16(a, (hipStream_t)stream);
+}
+
+int mi355_pool_linear(const float* fm, int B, int C, int HW, const float* weight, const float* bias, int N, float* out,
+                      float* pooled_out, void* stream) {
+    MI355_REQUIRE(fm && (out || pooled_out), "pool_linear: null pointer");
+    MI355_REQUIRE(B >= 1 && C >= 1 && HW >= 1, "pool_linear: bad shape B=%d C=%d HW=%d", B, C, HW);
+    MI355_REQUIRE(!weight || (N >= 1 && out), "pool_linear: a weight needs N >= 1 and an output");
+    return launch_pool_linear(fm, weight, bias, out, pooled_out, B, C, HW, weight ? N : 0, (hipStream_t)stream);
 }
 
 int mi355_square_pad_normalize(const unsigned char* img, int h, int w, int fill, const float* mean, const float* stdv,

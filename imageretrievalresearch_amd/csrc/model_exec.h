@@ -83,9 +83,13 @@ struct ExecCtx {
     mi355_model* m;
     hipStream_t st;
     int nb, H, W;          // chunk batch, input size
-    const float* x;        // chunk input (NCHW fp32)
+    const float* x;        // chunk input (NCHW fp32), or null when the chunk comes as uint8 images:
     int b0, B;             // chunk offset / full batch (for taps)
     int lane = 0;          // which arena copy / internal stream this chunk uses
+    const unsigned char* x_u8 = nullptr;   // [nb][img_h][img_w][3] (fused pre-processing + stem)
+    int img_h = 0, img_w = 0, fill = 255;
+    float mean[3] = {0.f, 0.f, 0.f}, stdv[3] = {1.f, 1.f, 1.f};
+    const float* conv_w = nullptr;          // optional conv_input weights (device)
     char* base() const { return (char*)m->arena + (size_t)lane * m->lane_bytes; }
     void* slot_ptr(int s) const { return s == SLOT_NONE ? nullptr : base() + m->slots[s].off; }
     const char* w(size_t off) const { return (const char*)m->dev_blob + off; }

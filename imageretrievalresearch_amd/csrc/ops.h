@@ -70,6 +70,12 @@ int launch_mbconv_block(const BlockArgs& a, int B, int k, int stride, hipStream_
 int launch_stem(const float* x, const float* w, const float* bias, bf16_t* out, int B, int H, int W, int Cout,
                 int act, hipStream_t st);
 
+// Fused input + stem: img [B][h][w][3] uint8 -> SquarePad(fill) / ToTensor / Normalize (host mean / std) -> optional
+// conv_input (conv_w: device fp32 [3][3][3][3], null = none) + SiLU -> stem; out [B][S/2][S/2][Cout] bf16, S = max(h, w).
+int launch_stem_u8(const unsigned char* img, int h, int w, int fill, const float* mean, const float* stdv,
+                   const float* conv_w, const float* sw, const float* bias, bf16_t* out, int B, int Cout, int act,
+                   hipStream_t st);
+
 // Depthwise k x k (k = 3 or 5), stride 1 or 2, pad k/2.  w [k*k][C] bf16, bias fp32 [C].
 // pool_partial (optional): [B][dw_pool_blocks(...)][C] fp32 partial sums of the un-rounded output
 // (the SE squeeze), reduced in a fixed order.
@@ -85,6 +91,11 @@ int launch_se(const float* pool_partial, int nblk, float inv_hw, const float* w1
 
 // Global average pool of NHWC bf16 -> pooled fp32 [B][C] (+ optional bf16 copy for the classifier GEMM).
 int launch_gap(const bf16_t* in, float* pooled, bf16_t* pooled_bf16, int B, int HW, int C, hipStream_t st);
+
+// ClassifierHead on an un-pooled NCHW fp32 map: pooled_out (optional) [B][C] fp32 = mean over HW; out (when w != null) [B][N]
+// = Linear(bf16(pooled); bf16(w) [N][C], bias [N] or null) with fp32 accumulation.
+int launch_pool_linear(const float* fm, const float* w, const float* bias, float* out, float* pooled_out, int B, int C,
+                       int HW, int N, hipStream_t st);
 
 // NHWC bf16 [B][HW][C] -> NCHW fp32 [B][Cvalid][HW] (forward_features output, taps).
 int launch_nhwc_to_nchw_f32(const bf16_t* in, float* out, int B, int HW, int C, int Cvalid, hipStream_t st);

@@ -45,17 +45,42 @@ class _Node(nn.Module):
 
 class ClassifierHead(nn.Module):
     """timm's rexnet ``ClassifierHead``: global-avg-pool + fc; callable on the un-pooled map
-    (train/train.py:195 ``self.model.head(fm)``).  Stand-alone calls use torch ops; inside
-    ``model(x)`` the pooled GEMM runs in the HIP path."""
+    (train/train.py:194-195 ``fm = self.model.forward_features(x); lbl = self.model.head(fm)``).  The call runs in the HIP
+    library (``mi355_pool_linear``: pool + Linear in one kernel, same rounding points as the classifier inside
+    ``model(x)``); like every op of the package it has no CPU path."""
 
     def __init__(self, in_features, num_classes):
         super().__init__()
         self.fc = nn.Linear(in_features, num_classes) if num_classes > 0 else nn.Identity()
 
     def forward(self, x):
-        if x.dim() == 4:
-            x = x.mean((2, 3))
-        return self.fc(x)
+        return pool_linear(x, self.fc)
+
+
+def pool_linear(fm: torch.Tensor, fc: "nn.Module | None" = None) -> torch.Tensor:
+    """``get_fm`` (train/train.py:84-103) when ``fc`` is None / Identity, else ``fc(get_fm(fm))`` for an nn.Linear ``fc``:
+    fm (B, C, H, W) fp32 on the GPU -> (B, C) or (B, N)."""
+    require_cuda(fm, "feature map")
+    if fm.dim() != 4:
+        raise MI355Error(f"expected an un-pooled (B, C, H, W) map, got {tuple(fm.shape)}")
+    fm = fm.detach().float().contiguous()
+    B, Cc, H, W = fm.shape
+    lin = fc if isinstance(fc, nn.Linear) else None
+    if fc is not None and lin is None and not isinstance(fc, nn.Identity):
+        raise MI355Error("pool_linear: the head must be nn.Linear or nn.Identity")
+    if lin is not None and lin.in_features != Cc:
+        raise MI355Error(f"head expects {lin.in_features} features, the map has {Cc}")
+    out = torch.empty((B, lin.out_features if lin is not None else Cc), dtype=torch.float32, device=fm.device)
+    if B:
+        w = lin.weight.detach().to(fm.device, torch.float32).contiguous() if lin is not None else None
+        bia = lin.bias.detach().to(fm.device, torch.float32).contiguous() if (lin is not None and lin.bias is not None) else None
+        with torch.cuda.device(fm.device):
+            check(lib().mi355_pool_linear(fm.data_ptr(), B, Cc, H * W, w.data_ptr() if w is not None else None,
+                                          bia.data_ptr() if bia is not None else None,
+                                          lin.out_features if lin is not None else 0,
+                                          out.data_ptr() if lin is not None else None,
+                                          out.data_ptr() if lin is None else None, stream_ptr(fm.device)))
+    return out
 
 
 def _swin_relative_position_index(ws: int) -> torch.Tensor:
@@ -370,6 +395,41 @@ class MI355Model(nn.Module):
             head = nxt
         if not isinstance(head, (nn.Linear, nn.Identity, ClassifierHead)):
             out = head(out)
+        return out
+
+    def forward_uint8(self, images: torch.Tensor, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225),
+                      fill: int = 255, conv_input: "nn.Module | None" = None, features: bool = False) -> torch.Tensor:
+        """The reference's whole inference front end in ONE kernel in front of the backbone: ``images`` (B, h, w, 3) uint8
+        on the GPU (one size per batch) -> SquarePad(fill) -> ToTensor -> Normalize(mean, std) (inference/inference.py:48-52)
+        -> ``conv_input`` (the ``Sequential(Conv2d(3,3,3,1,1,bias=False), SiLU)`` of inference/inference.py:103-105, or
+        None) -> stem ... -> ``forward`` (or ``forward_features`` with ``features=True``).  No fp32 NCHW batch is ever
+        written; bit-identical to ``preprocess.square_pad_normalize`` + ``conv_input`` + ``forward``."""
+        require_cuda(images, "images")
+        if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[3] != 3:
+            raise MI355Error(f"forward_uint8 expects uint8 (B, h, w, 3), got {images.dtype} {tuple(images.shape)}")
+        if self.family == "swin":
+            raise MI355Error("forward_uint8: swin has no 3x3 stem to fuse the pre-processing into")
+        images = images.contiguous()
+        self._ensure_packed(images.device)
+        B, h, w, _ = images.shape
+        S = max(h, w)
+        cw = None
+        if conv_input is not None:
+            conv = conv_input[0] if isinstance(conv_input, nn.Sequential) else getattr(conv_input, "conv", conv_input)
+            if not isinstance(conv, nn.Conv2d) or tuple(conv.weight.shape) != (3, 3, 3, 3) or conv.bias is not None:
+                raise MI355Error("conv_input must be Sequential(Conv2d(3, 3, 3, 1, 1, bias=False), SiLU)")
+            cw = conv.weight.detach().to(images.device, torch.float32).contiguous()
+        D = self.num_features
+        if features:
+            out = torch.empty((B, D, (S + 31) // 32, (S + 31) // 32), dtype=torch.float32, device=images.device)
+        else:
+            out = torch.empty((B, self.num_classes if self.num_classes > 0 else D), dtype=torch.float32, device=images.device)
+        m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+        if B:
+            with torch.cuda.device(images.device):
+                check(lib().mi355_model_forward_u8(self._handle, images.data_ptr(), B, h, w, int(fill), m3, s3,
+                                                   cw.data_ptr() if cw is not None else None, int(features),
+                                                   out.data_ptr(), None, stream_ptr(images.device)))
         return out
 
     def embed(self, x: torch.Tensor):

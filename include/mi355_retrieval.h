@@ -151,6 +151,17 @@ int mi355_model_forward_features(mi355_model_t m, const float* x, int B, int H, 
 int mi355_model_forward(mi355_model_t m, const float* x, int B, int H, int W, float* out,
                         float* pooled_out, void* stream);
 
+/* The same forward with the pre-processing fused into the stem's input load: images
+ * [B][h][w][3] uint8 on the device (one size for the batch) -> SquarePad(fill) (utils/square_pad.py:20-36) -> ToTensor
+ * (/255) -> Normalize(mean, std: HOST float[3]) (inference/inference.py:48-52) -> optional conv_input (conv_input_w:
+ * DEVICE fp32 [3][3][3][3] as Conv2d(3,3,3,1,1,bias=False).weight, NULL = none) + SiLU (inference/inference.py:101-105)
+ * -> stem, in ONE kernel: no fp32 NCHW batch is written.  Output as mi355_model_forward (features_only = 0) or
+ * mi355_model_forward_features (1) for an S x S input, S = max(h, w).  Bit-identical to running the separate
+ * mi355_square_pad_normalize / mi355_conv_input_silu / forward chain.  Conv backbones only (efficientnet, rexnet). */
+int mi355_model_forward_u8(mi355_model_t m, const unsigned char* images, int B, int h, int w, int fill,
+                           const float* mean, const float* stdv, const float* conv_input_w, int features_only,
+                           float* out, float* pooled_out, void* stream);
+
 /* Debug/parity tap: copy the bf16 NHWC activation the executor produced for layer `tap_name`
  * (e.g. "stem", "blocks.1.0") during the LAST forward into out as fp32 NCHW.  Taps are recorded
  * only after mi355_model_enable_taps(m, 1). */
@@ -195,6 +206,13 @@ int mi355_model_profile_ops(mi355_model_t m, int B, int H, int W, int max_ops, d
  * buckets are listed at the end of k_mbconv_block (csrc/mbconv_block.hip).  Synchronises the device.  Returns the number
  * of ops (size out with 16 * max_ops doubles, max_ops >= that; 1024 is always enough) or a negative error.  Developer tool. */
 int mi355_model_block_stamps(mi355_model_t m, double* out, int max_ops);
+
+/* timm ClassifierHead / get_fm on an un-pooled map (train/train.py:84-103 get_fm; :194-195 fm = forward_features(x);
+ * lbl = model.head(fm)): fm [B][C][HW] fp32 NCHW (device) -> pooled_out (optional) [B][C] fp32 global average ->
+ * out [B][N] = Linear(weight [N][C] fp32 device, bias [N] or NULL) on the bf16-rounded pooled features with bf16-rounded
+ * weights and fp32 accumulation (the rounding points of the in-model classifier).  weight NULL: pooling only. */
+int mi355_pool_linear(const float* fm, int B, int C, int HW, const float* weight, const float* bias, int N, float* out,
+                      float* pooled_out, void* stream);
 
 /* Stand-alone 1x1-conv / linear kernel (the model executor's GEMM): out[M][N] bf16 = act(A[M][K] bf16 * W^T + bias).
  * W is bf16 [ceil16(N)][ldw] with ldw = K rounded up to 32, zero padded; bias fp32 [ceil16(N)]; K, N multiples of 8.

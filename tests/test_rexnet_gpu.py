@@ -38,11 +38,15 @@ def test_rexnet_blocks_and_embedding_match_oracle(name, wm):
     print(name, "worst tap rel L2", worst)
     assert got.shape == want.shape and rel(got.cpu(), want) < TOL_TAP_SIM
     # train/train.py:194-195 call shape: fm = forward_features(x); lbl = head(fm)
-    lbl = model.head(got)
+    lbl = model.head(got)                          # ClassifierHead -> mi355_pool_linear (HIP), not torch eager
     assert lbl.shape == (2, 1000)
     want_logits = rexnet.forward(sd, x, wm, sim_bf16=True)
     out = model(x.to(DEV))
     assert rel(out.cpu(), want_logits) < 3e-2
+    assert rel(lbl.cpu(), want_logits) < 3e-2      # forward_features -> head(fm) == model(x), both against the oracle
+    assert rel(lbl.cpu(), out.cpu()) < 2e-3        # same rounding points, different summation order
+    pooled_only = M.models.pool_linear(got)        # get_fm (train/train.py:84-103)
+    assert torch.equal(pooled_only, model.embed(x.to(DEV))[0])
     f32 = rexnet.forward_features(sd, x, wm).mean((2, 3))
     pooled, _ = model.embed(x.to(DEV))
     assert rel(pooled.cpu(), f32) < TOL_EMB_FP32
