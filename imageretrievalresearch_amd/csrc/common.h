@@ -31,6 +31,17 @@ enum { OK = 0, ERR_ARG = 1, ERR_HIP = 2, ERR_STATE = 3, ERR_UNSUPPORTED = 4 };
 
 #define MI355_LAUNCH_CHECK() MI355_CHECK_HIP(hipGetLastError())
 
+// Per-device one-shot (e.g. hipFuncSetAttribute, which applies to the code object loaded on ONE device): true the first
+// time it is asked for the current device.  `flags` is a static bool[MI355_MAX_DEVICES] owned by the call site.
+constexpr int MI355_MAX_DEVICES = 64;
+static inline bool first_time_on_this_device(bool* flags) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MI355_MAX_DEVICES) return true;   // unknown: just redo it
+    if (flags[dev]) return false;
+    flags[dev] = true;
+    return true;
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 

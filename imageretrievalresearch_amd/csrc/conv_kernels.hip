@@ -474,11 +474,10 @@ static bool dw_tiled_plan(int H, int W, int C, int k, int stride, int* TH, int* 
 template <int KS, int PX>
 static int launch_dw_tiled(const bf16_t* in, const bf16_t* w, const float* bias, bf16_t* out, float* pool_partial, int B,
                            int H, int W, int C, int TH, int CGC, size_t lds, int act, int* pool_nblk, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[MI355_MAX_DEVICES] = {false};   // per device
+    if (first_time_on_this_device(attr_done)) {
         MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_dw_tiled<KS, PX>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             64 * 1024));
-        attr_done = true;
     }
     const int nbands = cdiv(H, TH), nchunks = cdiv(C / 8, CGC);
     hipLaunchKernelGGL((k_dw_tiled<KS, PX>), dim3(nbands * nchunks, B), dim3(256), lds, st, in, w, bias, out, pool_partial,

@@ -535,11 +535,10 @@ int fused_band_rows(int H, int W, int Cin, int mid, int k, int stride) {
 template <int KS, int S, int KST, int PX, int MC>
 static int launch_fb(const FusedArgs& a, int B, hipStream_t st) {
     const size_t lds = band_lds_bytes(a.W, a.Kp, KS, S, a.TH, PX, MC);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[MI355_MAX_DEVICES] = {false};   // per device
+    if (first_time_on_this_device(attr_done)) {
         MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_fused_band<KS, S, KST, PX, MC>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
     }
     hipLaunchKernelGGL((k_fused_band<KS, S, KST, PX, MC>), dim3(cdiv(a.Ho, a.TH), B), dim3(FL_THREADS), lds, st, a);
     MI355_LAUNCH_CHECK();
@@ -590,11 +589,10 @@ template <int KS, int S, int NIW, int PX>
 static int launch_fl(const FusedArgs& a, int B, hipStream_t st) {
     constexpr int MC = 128 * NIW;
     const size_t lds = fused_lds_bytes(a.H, a.W, a.Kp, MC, KS, S);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[MI355_MAX_DEVICES] = {false};   // per device
+    if (first_time_on_this_device(attr_done)) {
         MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_fused_late<KS, S, NIW, PX>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
     }
     const int nchunks = cdiv(a.mid, MC);
     int G = 256 / (B > 0 ? B : 1);

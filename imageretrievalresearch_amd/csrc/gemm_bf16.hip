@@ -522,11 +522,10 @@ _Pragma("unroll")
 template <bool GATED, bool KTAIL>
 static int launch_big(const GemmArgs& a, hipStream_t st) {
     const size_t lds = (size_t)BG_BM * (BG_BN + 4) * 4;   // 67.6 KB: fp32 epilogue tile (>= the 64 KB of stage buffers)
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[MI355_MAX_DEVICES] = {false};   // per device
+    if (first_time_on_this_device(attr_done)) {
         MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_big<GATED, KTAIL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds));
-        attr_done = true;
     }
     const int n_tiles = cdiv(a.N, BG_BN), m_tiles = cdiv(a.M, BG_BM);
     const long nwg = (long)n_tiles * m_tiles;
@@ -662,11 +661,10 @@ _Pragma("unroll")
 template <int NT, int KST>
 static int launch_stream_cfg(const GemmArgs& a, hipStream_t st) {
     const size_t lds = (size_t)NT * 16 * (KST * 32 + 8) * 2 + (size_t)4 * 16 * (NT * 16 + 8) * 2 + (size_t)NT * 16 * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[MI355_MAX_DEVICES] = {false};   // per device
+    if (first_time_on_this_device(attr_done)) {
         MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_stream<NT, KST>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        attr_done = true;
     }
     const int nslabs = cdiv(a.M, 16);
     int blocks = cdiv(nslabs, 4);
@@ -712,11 +710,10 @@ static int launch_cfg(const GemmArgs& a, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = NT * 16, LD = BK + 8;
     constexpr size_t stage = (size_t)2 * (BM + BN) * LD * 2, ctile = (size_t)BM * (BN + 8) * 2;
     constexpr size_t lds = stage > ctile ? stage : ctile;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[MI355_MAX_DEVICES] = {false};   // per device
+    if (first_time_on_this_device(attr_done)) {
         MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_bf16<WM, NT, BK>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
     }
     const int n_tiles = cdiv(a.N, BN);
     const int m_tiles = cdiv(a.M, BM);

@@ -184,6 +184,17 @@ static size_t plan_slots(mi355_model* m, int nb, int H, int W) {
 }
 
 static int ensure_arena(mi355_model* m, size_t bytes) {
+    int dev = 0;
+    MI355_CHECK_HIP(hipGetDevice(&dev));
+    if (m->arena && m->arena_device != dev) {      // the model moved to another GPU: its scratch must follow
+        MI355_CHECK_HIP(hipDeviceSynchronize());
+        (void)hipFree(m->arena);                   // (hipFree finds the owning device by itself)
+        m->arena = nullptr;
+        m->arena_bytes = 0;
+        for (auto& kv : m->tapbufs) { if (kv.second.ptr) (void)hipFree(kv.second.ptr); kv.second = TapBuf(); }
+        if (m->stamp_buf) { (void)hipFree(m->stamp_buf); m->stamp_buf = nullptr; m->stamp_bytes = 0; }
+    }
+    m->arena_device = dev;
     if (bytes <= m->arena_bytes) return OK;
     if (m->arena) {
         MI355_CHECK_HIP(hipDeviceSynchronize());
@@ -617,11 +628,14 @@ int mi355_model_pack(mi355_model_t m, void* stream) {
         if (int e = pack_gemm(pk, m->def.classifier)) return e;
     const size_t bytes = align_up(m->blob.size(), 256);
     m->blob.resize(bytes, 0);
-    if (bytes > m->dev_blob_bytes) {
+    int dev = 0;
+    MI355_CHECK_HIP(hipGetDevice(&dev));
+    if (bytes > m->dev_blob_bytes || dev != m->blob_device) {   // (re-)allocate on the CURRENT device
         if (m->dev_blob) MI355_CHECK_HIP(hipFree(m->dev_blob));
         m->dev_blob = nullptr;
         MI355_CHECK_HIP(hipMalloc(&m->dev_blob, bytes));
         m->dev_blob_bytes = bytes;
+        m->blob_device = dev;
     }
     hipStream_t st = (hipStream_t)stream;
     MI355_CHECK_HIP(hipMemcpyAsync(m->dev_blob, m->blob.data(), bytes, hipMemcpyHostToDevice, st));
@@ -904,12 +918,15 @@ int mi355_gemm_bf16(const void* A, const void* W, const float* bias, void* out, 
     GemmArgs a{};
     a.A = (const bf16_t*)A; a.lda = K; a.W = (const bf16_t*)W; a.ldw = ldw; a.bias = bias;
     a.out = out; a.ldo = N; a.out_f32 = 0; a.M = M; a.N = N; a.K = K; a.act = act; a.rows_per_img = 1; a.res_n = N;
-    static void* zero_page = nullptr;   // one 256-byte zero page per process for the DMA kernel's out-of-range chunks
-    if (!zero_page) {
-        MI355_CHECK_HIP(hipMalloc(&zero_page, 256));
-        MI355_CHECK_HIP(hipMemset(zero_page, 0, 256));
+    static void* zero_page[MI355_MAX_DEVICES] = {nullptr};   // a 256-byte zero page per device for the DMA kernel's out-of-range chunks
+    int dev = 0;
+    MI355_CHECK_HIP(hipGetDevice(&dev));
+    MI355_REQUIRE(dev >= 0 && dev < MI355_MAX_DEVICES, "gemm_bf16: device ordinal %d out of range", dev);
+    if (!zero_page[dev]) {
+        MI355_CHECK_HIP(hipMalloc(&zero_page[dev], 256));
+        MI355_CHECK_HIP(hipMemset(zero_page[dev], 0, 256));
     }
-    a.zeros = (const bf16_t*)zero_page;
+    a.zeros = (const bf16_t*)zero_page[dev];
     return launch_gemm_bf16(a, (hipStream_t)stream);
 }
 

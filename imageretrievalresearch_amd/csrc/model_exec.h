@@ -49,6 +49,7 @@ struct mi355_model {
     bool packed = false;
     void* arena = nullptr;
     size_t arena_bytes = 0;
+    int arena_device = -1, blob_device = -1;   // HIP device ordinals the arena / packed weights were allocated on
     SlotState slots[SLOT_COUNT];
     int microbatch = 0;
     int lanes = 1;              // option "lanes": chunks of a forward run concurrently on this many internal HIP streams (1 = caller's stream only)

@@ -26,16 +26,24 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
 
 
 class _Workspace:
-    """Per-device scratch that only grows; reused across calls (no hipMalloc on the hot path)."""
+    """Scratch that only grows, one buffer per (device, stream): calls issued on different streams (bench.py runs the rank
+    beside the embed) never share a workspace, and a buffer that is replaced by a bigger one is handed back to torch's
+    caching allocator on the stream that used it (``record_stream``), so it is not recycled under a running kernel."""
 
     def __init__(self):
         self.buf = {}
 
     def get(self, device, nbytes: int) -> torch.Tensor:
-        b = self.buf.get(device)
+        device = torch.device(device)
+        stream = torch.cuda.current_stream(device)
+        key = (device, stream.cuda_stream)
+        b = self.buf.get(key)
         if b is None or b.numel() < nbytes:
-            b = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-            self.buf[device] = b
+            if b is not None:
+                b.record_stream(stream)
+            with torch.cuda.stream(stream):
+                b = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self.buf[key] = b
         return b
 
 

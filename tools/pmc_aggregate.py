@@ -1,23 +1,31 @@
-"""Fold two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of tools/pmc_run.py into per-kernel-family HBM bytes.
+"""Fold rocprofv3 PMC passes of tools/pmc_run.py into HBM bytes / pipe-busy figures per kernel family and per launch.
 
-    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 tools/pmc_run.py efficientnet_b3a 256
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 tools/pmc_run.py efficientnet_b3a 256 labels.json
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 tools/pmc_run.py efficientnet_b3a 256
-    python tools/pmc_aggregate.py gpurun_out/pmc_fetch gpurun_out/pmc_write 3 > profiles/rNN_pmc_traffic_effnet_b256.json
+    rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES ... -d gpurun_out/pmc_sq -- python3 tools/pmc_run.py efficientnet_b3a 256
+    python tools/pmc_aggregate.py --fetch gpurun_out/pmc_fetch --write gpurun_out/pmc_write [--sq gpurun_out/pmc_sq]
+           --labels labels.json --sha <csrc fingerprint> > profiles/rNN_pmc_traffic_effnet_b256.json
 
-The third argument is the number of forwards the workload ran (pmc_run.py: 3).  Correction (MI355X_MICROARCH.md, HBM
-section): both counters are in KiB and gfx950's FETCH_SIZE reports half of a wide coalesced stream, so
-hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
+Correction (MI355X_MICROARCH.md, HBM section): both size counters are in KiB and gfx950's FETCH_SIZE reports half of a wide
+coalesced stream, so hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  Per-launch attribution: the op kernels of a forward
+(stem / GEMM / depthwise / SE / fused / whole-block) are launched in plan order, the same in every forward; the labels file
+lists them in that order.
 """
+import argparse
 import csv
 import glob
 import json
 import os
-import sys
+
+OP_KERNELS = ("k_stem", "k_gemm", "k_dwconv", "k_dw_tiled", "k_se", "k_fused", "k_mbconv_block", "k_win_attn", "k_layernorm",
+              "k_patch_embed", "k_ln_token_mean")
 
 
 def family(name: str) -> str:
     if "k_gemm" in name:
         return "gemm"
+    if "k_mbconv_block" in name:
+        return "block"
     if "k_fused" in name:
         return "fused"
     if "k_dwconv" in name or "k_dw_tiled" in name:
@@ -33,39 +41,100 @@ def family(name: str) -> str:
     return "other"
 
 
-def read_pass(directory: str, counter: str):
-    tot, launches = {}, {}
+N_SE, N_SIMD = 32, 1024      # MI355X: 8 XCDs x 4 shader engines; 256 CUs x 4 SIMDs
+
+
+def derived(e):
+    """Utilisation figures from the SQ counters of one launch (or one family sum).  rocprofv3 sums a counter over its
+    hardware instances: SQ_BUSY_CYCLES has one instance per shader engine (so /32 = the launch's duration in shader clocks),
+    SQ_VALU_MFMA_BUSY_CYCLES one per SIMD (checked: = 16 cycles x SQ_INSTS_MFMA for the 16x16x32 bf16 MFMA), and
+    SQ_ACTIVE_INST_VALU / SQ_WAIT_ANY / SQ_WAVE_CYCLES count in units of 4 cycles summed over waves."""
+    busy = e.get("SQ_BUSY_CYCLES", 0.0) / N_SE
+    if busy <= 0:
+        return
+    e["shader_cycles"] = busy
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in e:
+        e["mfma_pipe_util"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / N_SIMD / busy
+    if "SQ_ACTIVE_INST_VALU" in e:
+        e["valu_pipe_util"] = 4.0 * e["SQ_ACTIVE_INST_VALU"] / N_SIMD / busy
+    if e.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in e:
+        e["wave_wait_frac"] = e["SQ_WAIT_ANY"] / e["SQ_WAVE_CYCLES"]
+    if e.get("SQ_WAVE_CYCLES"):
+        e["waves_per_simd_avg"] = 4.0 * e["SQ_WAVE_CYCLES"] / N_SIMD / busy
+
+
+def read_pass(directory):
+    """rows in dispatch order: (dispatch id, kernel name, {counter: value})"""
     files = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         raise SystemExit(f"no counter_collection.csv under {directory}")
+    disp = {}
     for f in files:
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
-                if row["Counter_Name"] != counter:
-                    continue
-                fam = family(row["Kernel_Name"])
-                tot[fam] = tot.get(fam, 0.0) + float(row["Counter_Value"])
-                launches[fam] = launches.get(fam, 0) + 1
-    return tot, launches
+                d = int(row["Dispatch_Id"])
+                e = disp.setdefault(d, [row["Kernel_Name"], {}])
+                e[1][row["Counter_Name"]] = e[1].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+    return [(d, disp[d][0], disp[d][1]) for d in sorted(disp)]
 
 
 def main():
-    fetch_dir, write_dir, forwards = sys.argv[1], sys.argv[2], float(sys.argv[3])
-    fetch, launches = read_pass(fetch_dir, "FETCH_SIZE")
-    write, _ = read_pass(write_dir, "WRITE_SIZE")
-    fams = {}
-    for fam in sorted(set(fetch) | set(write)):
-        f_kb, w_kb = fetch.get(fam, 0.0) / forwards, write.get(fam, 0.0) / forwards
-        n = launches.get(fam, 0) / forwards
-        hbm = (2.0 * f_kb + w_kb) * 1024.0
-        fams[fam] = {"launches_per_forward": n, "fetch_size_kb_raw": f_kb, "write_size_kb": w_kb,
-                     "hbm_bytes_per_forward": hbm, "hbm_bytes_per_launch": hbm / n if n else 0.0}
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--fetch", required=True)
+    ap.add_argument("--write", required=True)
+    ap.add_argument("--sq")
+    ap.add_argument("--labels")
+    ap.add_argument("--sha", default="")
+    ap.add_argument("--note", default="")
+    a = ap.parse_args()
+    labels = json.load(open(a.labels)) if a.labels else None
+    passes = {"fetch": read_pass(a.fetch), "write": read_pass(a.write)}
+    if a.sq:
+        passes["sq"] = read_pass(a.sq)
+    forwards = float(labels["forwards"]) if labels else 3.0
+    fams, per_op = {}, {}
+    for pname, rows in passes.items():
+        for _, kname, ctr in rows:
+            f = fams.setdefault(family(kname), {"launches": 0})
+            if pname == "fetch":
+                f["launches"] += 1
+            for c, v in ctr.items():
+                f[c] = f.get(c, 0.0) + v
+        if labels:
+            oprows = [r for r in rows if any(k in r[1] for k in OP_KERNELS)]
+            n = len(labels["launches"])
+            if len(oprows) % n == 0:
+                reps = len(oprows) // n
+                for i, lab in enumerate(labels["launches"]):
+                    e = per_op.setdefault(f"{i:03d} " + lab["label"], {"label": lab["label"], "kernel": oprows[i][1].split("(")[0][:80],
+                                                                         "ops_in_launch": lab["ops"], "algorithmic_bytes": lab["bytes"],
+                                                                         "hipevent_ms": lab["ms"]})
+                    for c in set().union(*[oprows[i + k * n][2].keys() for k in range(reps)]):
+                        e[c] = sum(oprows[i + k * n][2].get(c, 0.0) for k in range(reps)) / reps
+    out_f = {}
+    for fam, f in sorted(fams.items()):
+        n = f["launches"] / forwards
+        hbm = (2.0 * f.get("FETCH_SIZE", 0.0) + f.get("WRITE_SIZE", 0.0)) * 1024.0 / forwards
+        out_f[fam] = {"launches_per_forward": n, "fetch_size_kb_raw": f.get("FETCH_SIZE", 0.0) / forwards,
+                      "write_size_kb": f.get("WRITE_SIZE", 0.0) / forwards, "hbm_bytes_per_forward": hbm,
+                      "hbm_bytes_per_launch": hbm / n if n else 0.0}
+        for c, v in f.items():
+            if c.startswith("SQ_") or c.startswith("GRBM_"):
+                out_f[fam][c] = v / forwards
+        derived(out_f[fam])
+    ops = {}
+    for key, e in sorted(per_op.items()):
+        e["hbm_bytes_per_launch"] = (2.0 * e.get("FETCH_SIZE", 0.0) + e.get("WRITE_SIZE", 0.0)) * 1024.0
+        if e["algorithmic_bytes"]:
+            e["hbm_over_algorithmic"] = e["hbm_bytes_per_launch"] / e["algorithmic_bytes"]
+        derived(e)
+        ops[e["label"] if e["label"] not in ops else key] = e
     print(json.dumps({
-        "workload": " ".join(sys.argv[4:]) or "tools/pmc_run.py, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes",
-        "forwards": forwards,
+        "workload": a.note or "tools/pmc_run.py, rocprofv3 --pmc in separate passes (FETCH_SIZE | WRITE_SIZE | SQ counters)",
+        "forwards": forwards, "csrc_sha16": a.sha,
         "correction": "hbm = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE reports half of a wide coalesced "
                       "stream (MI355X_MICROARCH.md HBM section)",
-        "families": fams}, indent=1))
+        "families": out_f, "per_op": ops}, indent=1))
 
 
 if __name__ == "__main__":

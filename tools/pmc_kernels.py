@@ -1,0 +1,28 @@
+"""Per-kernel-name averages of the counters of one or more rocprofv3 --pmc passes (developer tool):
+    python tools/pmc_kernels.py <pass dir> [<pass dir> ...] > summary.json"""
+import csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pmc_aggregate import derived
+agg = {}
+for d in sys.argv[1:]:
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        per = {}
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                k = (row["Dispatch_Id"], row["Kernel_Name"].split("(")[0][:100])
+                per.setdefault(k, {})
+                per[k][row["Counter_Name"]] = per[k].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+        for (_, name), ctr in per.items():
+            e = agg.setdefault(name, {})
+            for c, v in ctr.items():
+                s = e.setdefault(c, [0.0, 0])
+                s[0] += v; s[1] += 1
+out = {}
+for name, e in sorted(agg.items()):
+    o = {c: s[0] / s[1] for c, s in e.items()}
+    o["dispatches"] = max(s[1] for s in e.values())
+    derived(o)
+    if "FETCH_SIZE" in o:
+        o["fetch_bytes_corrected"] = 2.0 * o["FETCH_SIZE"] * 1024.0
+    out[name] = o
+print(json.dumps(out, indent=1))
