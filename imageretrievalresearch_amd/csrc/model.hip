@@ -284,6 +284,11 @@ static int exec_op(ExecCtx& cx, const Op& op) {
     }
 }
 
+// row-sweep kernel (MFMA depthwise, complete squeeze sums): the early-stage shape classes of sweep_mbconv.hip
+static bool use_sweep(const mi355_model* m, const Op& g, const Op& d, int h, int w) {
+    return m->fuse_sweep && sweep_mbconv_supported(h, w, g.cin, g.cout, d.k, d.stride);
+}
+
 // expand GEMM (-> SLOT_E) immediately followed by the depthwise conv that consumes it, on a whole-image tile
 static bool can_fuse(const mi355_model* m, size_t i, int h, int w) {
     if (!m->fuse || i + 1 >= m->def.ops.size()) return false;
@@ -292,6 +297,7 @@ static bool can_fuse(const mi355_model* m, size_t i, int h, int w) {
     if (g.kind != OP_GEMM || d.kind != OP_DW || g.out != SLOT_E || d.in != SLOT_E) return false;
     if (g.use_gate || g.res != SLOT_NONE || g.a_relu6 || !g.tap.empty()) return false;
     if (fused_late_supported(h, w, g.cin, g.cout, d.k, d.stride)) return true;
+    if (use_sweep(m, g, d, h, w)) return true;
     // Band variant, measured per layer on EfficientNet-B3a B=256 (fused vs expand + depthwise): 3x3 s1 C192 @56x56 307 vs
     // 339 us (wins); 3x3 s2 C144 @112x112 780 vs 619, 5x5 s2 C192 @56x56 465 vs 276, 5x5 s1 C288 @28x28 247 vs 172 (lose:
     // short bands recompute too much halo and leave most threads idle in the depthwise phase).
@@ -317,6 +323,23 @@ static bool can_fuse_block(const mi355_model* m, size_t i, int h, int w, int nb)
     return mbconv_block_supported(h, w, g.cin, g.cout, p.cout, d.k, d.stride, s.rd);
 }
 
+// diagnosis buffer [ops][B][16] of cycle buckets (option "block_stamps"); *out stays null when the option is off
+static int stamp_ptr(ExecCtx& cx, size_t oi, long long** out) {
+    mi355_model* m = cx.m;
+    *out = nullptr;
+    if (!m->block_stamps) return OK;
+    const size_t need = m->def.ops.size() * (size_t)cx.B * 16 * sizeof(long long);
+    if (m->stamp_bytes < need) {
+        if (m->stamp_buf) MI355_CHECK_HIP(hipFree(m->stamp_buf));
+        MI355_CHECK_HIP(hipMalloc((void**)&m->stamp_buf, need));
+        m->stamp_bytes = need;
+    }
+    m->stamp_B = cx.B;
+    *out = m->stamp_buf + (oi * (size_t)cx.B + cx.b0) * 16;
+    MI355_CHECK_HIP(hipMemsetAsync(*out, 0, (size_t)cx.nb * 16 * sizeof(long long), cx.st));
+    return OK;
+}
+
 static int exec_block(ExecCtx& cx, size_t oi) {
     mi355_model* m = cx.m;
     SlotState* S = m->slots;
@@ -340,17 +363,7 @@ static int exec_block(ExecCtx& cx, size_t oi) {
     a.inv_hw = 1.0f / (float)(a.Ho * a.Wo);
     a.norot = m->block_norot;
     a.stamps = nullptr;
-    if (m->block_stamps) {
-        const size_t need = m->def.ops.size() * (size_t)cx.B * 16 * sizeof(long long);
-        if (m->stamp_bytes < need) {
-            if (m->stamp_buf) MI355_CHECK_HIP(hipFree(m->stamp_buf));
-            MI355_CHECK_HIP(hipMalloc((void**)&m->stamp_buf, need));
-            MI355_CHECK_HIP(hipMemsetAsync(m->stamp_buf, 0, need, cx.st));
-            m->stamp_bytes = need;
-        }
-        m->stamp_B = cx.B;
-        a.stamps = m->stamp_buf + (oi * (size_t)cx.B + cx.b0) * 16;
-    }
+    { const int rc = stamp_ptr(cx, oi, &a.stamps); if (rc != OK) return rc; }
     return launch_mbconv_block(a, cx.nb, d.k, d.stride, cx.st);
 }
 
@@ -369,6 +382,15 @@ static int exec_fused(ExecCtx& cx, const Op& g, const Op& d) {
     if (fused_late_supported(a.H, a.W, g.cin, g.cout, d.k, d.stride)) {
         m->pool_nblk = 1;
         return launch_fused_late(a, cx.nb, d.k, d.stride, cx.st);
+    }
+    if (use_sweep(m, g, d, a.H, a.W)) {
+        SweepArgs sa{};
+        sa.X = a.X; sa.We = a.We; sa.be = a.be; sa.Wd = a.Wd; sa.bd = a.bd; sa.D = a.D; sa.pool = a.pool;
+        sa.H = a.H; sa.W = a.W; sa.Cin = a.Cin; sa.Kp = a.Kp; sa.mid = a.mid; sa.Ho = a.Ho; sa.Wo = a.Wo;
+        sa.act_e = a.act_e; sa.act_d = a.act_d; sa.csplit_override = m->sweep_csplit; sa.variant = m->sweep_variant; sa.debug_skip = m->sweep_skip;
+        { const int rc = stamp_ptr(cx, (size_t)(&g - m->def.ops.data()), &sa.stamps); if (rc != OK) return rc; }
+        m->pool_nblk = 1;
+        return launch_sweep_mbconv(sa, cx.nb, d.k, d.stride, cx.st);
     }
     a.TH = fused_band_rows(a.H, a.W, g.cin, g.cout, d.k, d.stride);
     m->pool_nblk = cdiv(a.Ho, a.TH);
@@ -735,6 +757,10 @@ int mi355_model_set_option(mi355_model_t m, const char* key, int64_t value) {
     else if (k == "lanes") m->lanes = (int)value;
     else if (k == "fuse") m->fuse = value != 0;
     else if (k == "fuse_band") m->fuse_band = (int)value;
+    else if (k == "fuse_sweep") m->fuse_sweep = (int)value;
+    else if (k == "sweep_csplit") m->sweep_csplit = (int)value;
+    else if (k == "sweep_variant") m->sweep_variant = (int)value;
+    else if (k == "sweep_skip") m->sweep_skip = (int)value;
     else if (k == "fuse_debug") m->fuse_debug = (int)value;
     else if (k == "fuse_block") m->fuse_block = (int)value;
     else if (k == "fuse_block_min_batch") m->fuse_block_min_batch = (int)value;

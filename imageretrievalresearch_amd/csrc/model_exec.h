@@ -56,6 +56,10 @@ struct mi355_model {
     hipStream_t lane_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t lane_fork = nullptr, lane_join[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t lane_bytes = 0;      // arena bytes per lane
+    int fuse_sweep = 1;         // row-sweep kernel (sweep_mbconv.hip, MFMA depthwise) for the early-stage shapes it supports:
+                                // 0 never, 1 (default) the shape classes measured faster than the alternatives
+    int sweep_variant = 0, sweep_skip = 0;   // tuning / diagnosis knobs of the row-sweep kernel
+    int sweep_csplit = 0;       // tuning: workgroups per image in the row-sweep kernel (0 = launcher's choice)
     int fuse_band = 2;          // band variant for the early stages: 0 never, 1 wherever it fits, 2 (default) only the shape
                                 // classes where it was measured faster than the unfused pair (see can_fuse in model.hip)
     bool fuse = true;           // fused expand+depthwise for whole-image tiles (option "fuse")

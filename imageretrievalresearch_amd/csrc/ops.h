@@ -43,6 +43,26 @@ int launch_fused_late(const FusedArgs& a, int B, int k, int stride, hipStream_t 
 int fused_band_rows(int H, int W, int Cin, int mid, int k, int stride);   // 0 = unsupported
 int launch_fused_band(const FusedArgs& a, int B, int k, int stride, hipStream_t st);
 
+// ---- row-sweep front half for the early stages (sweep_mbconv.hip): expand -> MFMA depthwise -> D + complete squeeze sums
+struct SweepArgs {
+    const bf16_t* X;      // [B][H][W][Cin] block input
+    const bf16_t* We;     // expand weights, GEMM packing [midPad16][Kp]
+    const float* be;      // expand bias [midPad16]
+    const bf16_t* Wd;     // depthwise weights [k*k][mid]
+    const float* bd;      // depthwise bias [mid]
+    bf16_t* D;            // [B][Ho][Wo][mid] depthwise output
+    float* pool;          // optional [B][mid]: complete per-channel sums of D (SE squeeze, nblk = 1)
+    int B, H, W, Cin, Kp, mid, Ho, Wo;
+    int act_e, act_d;
+    int csplit;           // workgroups per image (set by the launcher)
+    int csplit_override;  // > 0: tuning override
+    int variant;          // tuning: alternative band height / occupancy class (0 = default)
+    int debug_skip;       // diagnosis only: bit0 skip the expand phase, bit1 skip the depthwise phase, bit2 skip the X loads
+    long long* stamps;    // diagnosis only: [B][16] cycle buckets, summed over the image's workgroups (wave 0's view)
+};
+bool sweep_mbconv_supported(int H, int W, int Cin, int mid, int k, int stride);
+int launch_sweep_mbconv(const SweepArgs& a, int B, int k, int stride, hipStream_t st);
+
 // ---- whole MBConv block for the late stages (mbconv_block.hip): expand -> depthwise -> SE -> gated projection (+ residual)
 struct BlockArgs {
     const bf16_t* X;                      // [B][H][W][Cin] block input (also the residual)
