@@ -189,7 +189,10 @@ int mi355_model_traffic_kinds(mi355_model_t m, int B, int H, int W, double* byte
 /* Executor options: "microbatch" (images per pass through the layer plan; 0 = whole batch),
  * "fuse" (1 = run expand+depthwise pairs on whole-image tiles as one LDS-resident kernel; default 1),
  * "fuse_block" (1 = run whole MBConv blocks of the 14x14 / 7x7 stages - expand, depthwise, SE, gated projection, residual -
- *  as ONE kernel per block; default 1), "fuse_block_min_batch" (use it only for batches of at least this many images),
+ *  as ONE kernel per block; default 1), "fuse_block_min_batch" (use it only for batches of at least this many images;
+ *  default 192: one workgroup per image needs about a CU per image to win),
+ * "fuse_sweep" (1 = run expand+depthwise of the 112x112 .. 28x28 blocks with the row-sweep kernel, MFMA depthwise from an
+ *  LDS row window; default 1), "fuse_band" (older band kernel for shapes the row-sweep kernel does not cover),
  * "profile" (1 = bracket every op with hipEvents on the launch stream; resets the accumulators). */
 int mi355_model_set_option(mi355_model_t m, const char* key, int64_t value);
 /* Accumulated per-kind kernel time (ms) and launch counts since "profile" was enabled; synchronises. */

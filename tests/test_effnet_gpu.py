@@ -226,6 +226,7 @@ def test_block_kernel_agrees_with_the_unfused_chain(setup):
     x = torch.from_numpy(images(17, 3)).to(DEV)
     names = ["blocks.3.0", "blocks.3.1", "blocks.4.0", "blocks.5.0", "blocks.6.1", "head"]
     taps = {}
+    model.set_option("fuse_block_min_batch", 1)      # the default only picks the block kernel for >= 192 images
     for opt in (0, 1):
         model.set_option("fuse_block", opt)
         model.enable_taps(True)
@@ -240,7 +241,37 @@ def test_block_kernel_agrees_with_the_unfused_chain(setup):
         assert rel(taps[1][n], taps[0][n]) < 1.2e-2, n
     xx = x[:1].repeat(5, 1, 1, 1).contiguous()                            # same image at five batch positions
     out = model.forward_features(xx)
+    model.set_option("fuse_block_min_batch", 192)
     for i in range(1, 5):
+        assert torch.equal(out[0], out[i]), i
+
+
+def test_sweep_kernel_agrees_with_the_unfused_pair(setup):
+    """The row-sweep kernel (expand + MFMA depthwise of the 112x112 .. 28x28 blocks) against the expand GEMM and the
+    depthwise kernel run separately on the same weights: both round the expanded tensor to bf16 and accumulate the taps
+    in fp32, so the first swept block may differ by a few bf16 roundings only; nothing may depend on the batch position
+    (the kernel walks its channel slabs from an image-dependent start)."""
+    sd, model = setup
+    x = torch.from_numpy(images(23, 3)).to(DEV)
+    names = ["blocks.0.1", "blocks.1.0", "blocks.1.1", "blocks.2.0", "blocks.2.1", "blocks.3.0"]
+    taps = {}
+    for opt in (0, 1):
+        model.set_option("fuse_sweep", opt)
+        model.set_option("fuse_band", 0 if opt == 0 else 2)
+        model.enable_taps(True)
+        model.forward_features(x)
+        taps[opt] = {n: model.read_tap(n).cpu() for n in names}
+        model.enable_taps(False)
+    model.set_option("fuse_sweep", 1)
+    model.set_option("fuse_band", 2)
+    assert torch.equal(taps[0]["blocks.0.1"], taps[1]["blocks.0.1"])      # last block before the swept stages
+    first = rel(taps[1]["blocks.1.0"], taps[0]["blocks.1.0"])
+    assert first < 1e-3, first
+    for n in names[2:]:
+        assert rel(taps[1][n], taps[0][n]) < 6e-3, n
+    xx = x[:1].repeat(11, 1, 1, 1).contiguous()                           # same image at eleven batch positions (> 8 XCDs)
+    out = model.forward_features(xx)
+    for i in range(1, 11):
         assert torch.equal(out[0], out[i]), i
 
 
