@@ -108,7 +108,9 @@ template <int MT, int RK_BK, bool VEC, int FK>
 __global__ __launch_bounds__(256) void k_cos_gemm(const float* __restrict__ Qn, const float* __restrict__ Gal,
                                                   const float* __restrict__ ginv, float* __restrict__ S,
                                                   int Q, i64 G, int D, int k, float* __restrict__ cand_val,
-                                                  int* __restrict__ cand_idx) {
+                                                  int* __restrict__ cand_idx, int x0, int ntx) {
+    // x0 / ntx: this launch covers the column tiles [x0, x0 + gridDim.x) of ntx (the host splits a call into a main launch
+    // of whole rounds and a tail launch of smaller tiles)
     constexpr int BM = 64 * MT;
     constexpr int RK_LD = RK_BK + 4;      // +4 floats: ds_read_b128 of 16 distinct rows is bank-conflict free (36 and 20)
     constexpr int CPR = RK_BK / 4;        // float4 columns per row of a K-tile
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void k_cos_gemm(const float* __restrict__ Qn, 
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const i64 n0 = (i64)blockIdx.x * RK_BN;
+    const i64 n0 = (i64)(blockIdx.x + x0) * RK_BN;
     const int m0 = blockIdx.y * BM;
 
     const int c4 = tid % CPR;  // float4 column within the K-tile
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(256) void k_cos_gemm(const float* __restrict__ Qn, 
                 }
                 const int qrow = m0 + h * 64 + lrow;
                 if (part == 0 && qrow < Q) {
-                    const size_t o = ((size_t)qrow * gridDim.x + blockIdx.x) * k;
+                    const size_t o = ((size_t)qrow * ntx + blockIdx.x + x0) * k;
 #pragma unroll
                     for (int i = 0; i < FK; ++i)
                         if (i < k) { cand_val[o + i] = ki[i] == IDX32_PAD ? NEG_INF : key_score(kv[i]); cand_idx[o + i] = ki[i]; }
@@ -729,25 +731,59 @@ static RankWs carve(void* ws, i64 Q, i64 G, int D, int k, bool need_ginv, bool n
     return r;
 }
 
+// resident workgroups per CU x CUs of the current device for one instantiation (cached per device)
+template <int MT, int BK, bool VEC, int FK>
+static int gemm_slots(size_t lds, int* slots_out) {
+    static int slots[MI355_MAX_DEVICES] = {0};
+    int dev = 0;
+    MI355_CHECK_HIP(hipGetDevice(&dev));
+    MI355_REQUIRE(dev >= 0 && dev < MI355_MAX_DEVICES, "rank: device ordinal %d out of range", dev);
+    if (!slots[dev]) {
+        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_cos_gemm<MT, BK, VEC, FK>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int per_cu = 0, cus = 0;
+        MI355_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_cos_gemm<MT, BK, VEC, FK>, 256, lds));
+        MI355_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        slots[dev] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+    }
+    *slots_out = slots[dev];
+    return OK;
+}
+
+template <int MT, int BK>
+static size_t gemm_lds(bool fk) {
+    const size_t stage = (size_t)2 * (64 * MT + RK_BN) * (BK + 4) * sizeof(float);
+    const size_t tile = fk ? (size_t)64 * (RK_BN + 4) * sizeof(float) : 0;   // fused selection: 64 rows of the score tile at a time
+    return stage > tile ? stage : tile;
+}
+
 template <int MT, int BK, bool VEC, int FK>
 static int launch_gemm(const float* qn, const float* gal, const float* ginv, float* S, int Q, i64 G, int D, int k,
                        float* cand_val, int* cand_idx, hipStream_t st) {
     constexpr int BM = 64 * MT;
-    const size_t stage = (size_t)2 * (BM + RK_BN) * (BK + 4) * sizeof(float);
-    const size_t tile = FK > 0 ? (size_t)64 * (RK_BN + 4) * sizeof(float) : 0;   // fused selection: 64 rows of the score tile at a time
-    const size_t lds = stage > tile ? stage : tile;
-    static bool attr_done[64] = {false};  // per instantiation and device
-    int dev = 0;
-    MI355_CHECK_HIP(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !attr_done[dev]) {
-        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_cos_gemm<MT, BK, VEC, FK>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done[dev] = true;
+    const size_t lds = gemm_lds<MT, BK>(FK > 0);
+    int slots = 0;
+    if (int e = gemm_slots<MT, BK, VEC, FK>(lds, &slots)) return e;
+    const int ntx = cdiv(G, RK_BN), ny = cdiv(Q, BM);
+    int xm = ntx;
+    // Wave quantisation: 1564 tiles on 768 slots run as 2.04 rounds and the 28 tiles of the third round cost a whole round
+    // (0.15 ms of 0.83 at Q=256 x 100k).  Whole rounds go out as 128-row tiles, the remainder as a second launch of 64-row
+    // tiles (same column tiles, same k order: every score is bit-identical), which halves the tiles' length and doubles
+    // their number.
+    if (MT == 2 && (long)ntx * ny > slots && ((long)ntx * ny) % slots != 0) xm = (int)(((long)ntx * ny / slots) * slots / ny);
+    if (xm > 0) {
+        hipLaunchKernelGGL((k_cos_gemm<MT, BK, VEC, FK>), dim3((unsigned)xm, (unsigned)ny), dim3(256), lds, st, qn, gal, ginv, S,
+                           Q, G, D, k, cand_val, cand_idx, 0, ntx);
+        MI355_LAUNCH_CHECK();
     }
-    dim3 grid((unsigned)cdiv(G, RK_BN), (unsigned)cdiv(Q, BM));
-    hipLaunchKernelGGL((k_cos_gemm<MT, BK, VEC, FK>), grid, dim3(256), lds, st, qn, gal, ginv, S, Q, G, D, k, cand_val,
-                       cand_idx);
-    MI355_LAUNCH_CHECK();
+    if (xm < ntx) {
+        const size_t lds1 = gemm_lds<1, 32>(FK > 0);
+        int slots1 = 0;
+        if (int e = gemm_slots<1, 32, VEC, FK>(lds1, &slots1)) return e;
+        hipLaunchKernelGGL((k_cos_gemm<1, 32, VEC, FK>), dim3((unsigned)(ntx - xm), (unsigned)cdiv(Q, 64)), dim3(256), lds1, st,
+                           qn, gal, ginv, S, Q, G, D, k, cand_val, cand_idx, xm, ntx);
+        MI355_LAUNCH_CHECK();
+    }
     return OK;
 }
 
