@@ -10,6 +10,7 @@ namespace mi355 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void unpack8(u32x4 v, float* f) {
     f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
@@ -487,6 +488,270 @@ static int launch_dw_tiled(const bf16_t* in, const bf16_t* w, const float* bias,
     return OK;
 }
 
+// =====================================================================================
+// 3x3 stride-1 depthwise for NARROW layers (C <= 64: the 112x112 C40 / C24 maps of EfficientNet's first stage, RexNet's
+// C32) on the matrix pipe.  The direct kernel above spends 9 FMAs + unpacking per output on the VALU next to the SiLU
+// and ran at 2.3 TB/s (VALU 56 % busy, waves waiting 73 %).  Here one 16x16x32 MFMA computes one ROW of taps for 8
+// channels x 32 consecutive pixels: M = (pixel parity p, channel c), N = 16 pixel pairs, K = (t' = p + tap, channel) with
+// A[(p,c)][(t',c')] = [c == c'] * w[ky][t' - p][c] and B[(t',c)][n] = in[c][2n + t' - 1] - each lane loads the 8 channels
+// (16 B) of ONE input pixel straight from global as its B fragment, no LDS, three MFMAs per 8 x 32 outputs.
+// A wave owns one 8-channel unit (its A fragments are built once), the C/8 waves of a workgroup walk the same pixel
+// tiles together (they hit the same lines in L1), ~50 VGPRs so 8 waves per SIMD hide the load latency.  Rows above /
+// below the image fall outside the image's buffer resource and read as zero (hardware range check); the horizontal
+// wrap of the linear pixel index is masked per lane.  Squeeze sums: one partial per (workgroup, channel), fixed order.
+// =====================================================================================
+typedef __bf16 dw_bf16x8 __attribute__((ext_vector_type(8)));
+// NU = 8-channel units per wave: a wave does ALL units of its 32-pixel tile back to back, so the units' loads (different 16
+// bytes of the same 80-byte pixels) hit the lines the first unit pulled into L1.  (A wave per unit, the first version, sent
+// every load to L2 - 30 waves x 8 KB of lines against a 32 KB L1 - and ran at 1.3 TB/s.)
+template <int NU>
+__global__ __launch_bounds__(256, NU >= 5 ? 3 : (NU >= 4 ? 4 : 5)) void k_dw3_mfma(
+    const bf16_t* __restrict__ in, const bf16_t* __restrict__ w, const float* __restrict__ bias, bf16_t* __restrict__ out,
+    float* __restrict__ pool_partial, int B, int nblk, int H, int W, int C, int cu0, int act, unsigned magicW, int tiles_per_wg) {
+    __shared__ float red[4][NU * 8];
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int b = xcd + 8 * (seq / nblk), blk = seq - (seq / nblk) * nblk;
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int HW = H * W;
+    const int c0 = cu0 * 8;                                               // first channel of this launch's units
+    // A fragments: lane (m = fr -> parity pm = fr >> 3, channel c = fr & 7; k group fq = t') holds k = t'*8 + c', nonzero at c' = c
+    u32x4 dwf[NU][3];
+    {
+        const int pm = fr >> 3, c = fr & 7, t = fq - pm;
+        const int q = c >> 1;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                unsigned v = 0u;
+                if (t >= 0 && t < 3) v = w[(size_t)(ky * 3 + t) * C + c0 + u * 8 + c];
+                const unsigned word = (c & 1) ? (v << 16) : v;
+                dwf[u][ky] = (u32x4){q == 0 ? word : 0u, q == 1 ? word : 0u, q == 2 ? word : 0u, q == 3 ? word : 0u};
+            }
+    }
+    const int ch4 = (fq & 1) * 4, pp = fq >> 1;                            // this lane's 4 output channels / pixel parity
+    f32x4 bb[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) bb[u] = *reinterpret_cast<const f32x4*>(bias + c0 + u * 8 + ch4);
+    const bf16_t* img = in + (size_t)b * HW * C;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(img), 0, HW * C * 2, 0x00020000);
+    bf16_t* ob = out + (size_t)b * HW * C + c0 + ch4;
+    const int rowb = W * C * 2;
+    const int ntiles = (HW + 31) >> 5;
+    const int t_end = min(ntiles, (blk + 1) * tiles_per_wg);
+    float psum[NU][4];
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) psum[u][j] = 0.f;
+    for (int tile = blk * tiles_per_wg + wave; tile < t_end; tile += 4) {
+        const int q = tile * 32 + 2 * fr;                                  // first pixel of this lane's pair (linear index, even)
+        const int y = (int)__umulhi((unsigned)q, magicW);
+        const int x = q - y * W;
+        const bool colok = !(fq == 0 && x == 0) && !(fq == 3 && x == W - 2);
+        // byte offset of input pixel q + fq - 1 (this lane's B fragment for the middle row); negative / past the image = zero
+        const int off = colok ? (q + fq - 1) * C * 2 + c0 * 2 : 0x40000000;
+        u32x4 xv[NU][3];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            xv[u][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off - rowb + u * 16, 0, 0);
+            xv[u][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + u * 16, 0, 0);
+            xv[u][2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + rowb + u * 16, 0, 0);
+        }
+        const bool live = q + pp < HW;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            f32x4 acc = bb[u];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const dw_bf16x8*>(&dwf[u][ky]),
+                                                              *reinterpret_cast<const dw_bf16x8*>(&xv[u][ky]), acc, 0, 0, 0);
+            MI355_ACT_DISPATCH(act, {
+                acc.x = act_c<ACT>(acc.x); acc.y = act_c<ACT>(acc.y); acc.z = act_c<ACT>(acc.z); acc.w = act_c<ACT>(acc.w);
+            })
+            if (live) {
+                psum[u][0] += acc.x; psum[u][1] += acc.y; psum[u][2] += acc.z; psum[u][3] += acc.w;
+                u32x2 o;
+                o.x = pack2bf(acc.x, acc.y);
+                o.y = pack2bf(acc.z, acc.w);
+                *reinterpret_cast<u32x2*>(ob + (size_t)(q + pp) * C + u * 8) = o;
+            }
+        }
+    }
+    if (pool_partial) {
+        // fold the 16 pixel-pair lanes and the two parities, then the four waves (fixed orders)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) psum[u][j] += __shfl_xor(psum[u][j], o, 64);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) psum[u][j] += __shfl_xor(psum[u][j], 32, 64);
+            if (fr == 0 && fq < 2)
+                *reinterpret_cast<f32x4*>(&red[wave][u * 8 + ch4]) = (f32x4){psum[u][0], psum[u][1], psum[u][2], psum[u][3]};
+        }
+        __syncthreads();
+        if (threadIdx.x < NU * 8)
+            pool_partial[((size_t)b * nblk + blk) * C + c0 + threadIdx.x] =
+                ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    }
+}
+
+// Same arithmetic, wave-private LDS staging: the direct version's loads and stores move 16 B per lane at an 80-byte stride
+// (every instruction touches ~22 cache lines for 1 KB).  Here a wave copies the three 34-pixel row windows of its tile with
+// contiguous 16-byte loads (8 per lane instead of 15 scattered ones), reads the B fragments from LDS, and writes its 32
+// output pixels through LDS as one contiguous 32*C*2-byte run.  No barriers: a wave only touches its own LDS region, and
+// the LDS executes one wave's instructions in order.  The next tile's loads are requested before this tile's MFMAs.
+template <int NU>
+__global__ __launch_bounds__(256, NU >= 5 ? 3 : 4) void k_dw3_lds(
+    const bf16_t* __restrict__ in, const bf16_t* __restrict__ w, const float* __restrict__ bias, bf16_t* __restrict__ out,
+    float* __restrict__ pool_partial, int B, int nblk, int H, int W, int act, unsigned magicW, int tiles_per_wg) {
+    constexpr int C = NU * 8, PB = C * 2;                 // channels (the whole layer), bytes per pixel
+    constexpr int ROWB = 34 * PB;                         // one row window: pixels q0-1 .. q0+32
+    constexpr int NCH = 3 * ROWB / 16;                    // 16-byte chunks of the three windows
+    constexpr int NLD = (NCH + 63) / 64;                  // staging loads per lane
+    constexpr int OUTB = 32 * PB, NOC = OUTB / 16, NST = (NOC + 63) / 64;
+    constexpr int WS = 3 * ROWB + OUTB + NU * 16;         // LDS bytes per wave: windows | output tile | zeros
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * WS];
+    __shared__ float red[4][NU * 8];
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int b = xcd + 8 * (seq / nblk), blk = seq - (seq / nblk) * nblk;
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int HW = H * W;
+    unsigned char* Lw = lds + wave * WS;
+    unsigned char* Lo = Lw + 3 * ROWB;
+    unsigned char* Lz = Lo + OUTB;
+    if (lane < NU) *reinterpret_cast<u32x4*>(Lz + lane * 16) = (u32x4){0u, 0u, 0u, 0u};
+    u32x4 dwf[NU][3];
+    {
+        const int pm = fr >> 3, c = fr & 7, t = fq - pm;
+        const int q = c >> 1;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                unsigned v = 0u;
+                if (t >= 0 && t < 3) v = w[(size_t)(ky * 3 + t) * C + u * 8 + c];
+                const unsigned word = (c & 1) ? (v << 16) : v;
+                dwf[u][ky] = (u32x4){q == 0 ? word : 0u, q == 1 ? word : 0u, q == 2 ? word : 0u, q == 3 ? word : 0u};
+            }
+    }
+    const int ch4 = (fq & 1) * 4, pp = fq >> 1;
+    f32x4 bb[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) bb[u] = *reinterpret_cast<const f32x4*>(bias + u * 8 + ch4);
+    const bf16_t* img = in + (size_t)b * HW * C;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(img), 0, HW * PB, 0x00020000);
+    unsigned char* ob = reinterpret_cast<unsigned char*>(out + (size_t)b * HW * C);
+    const int rowb = W * PB;
+    const int ntiles = (HW + 31) >> 5;
+    const int t_end = min(ntiles, (blk + 1) * tiles_per_wg);
+    float psum[NU][4];
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) psum[u][j] = 0.f;
+    // staging chunk i of this lane: chunk id = lane + 64 i -> row window id / ROWB-relative byte
+    int s_goff[NLD], s_loff[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int ch = lane + 64 * i;
+        const int ky = ch / (ROWB / 16), rem = ch - ky * (ROWB / 16);
+        s_loff[i] = ch < NCH ? ky * ROWB + rem * 16 : -1;
+        s_goff[i] = ch < NCH ? (ky - 1) * rowb + rem * 16 - PB : 0x40000000;     // relative to the tile's first pixel
+    }
+    u32x4 sv[NLD];
+    auto stage_load = [&](int tile) {
+        const int base = tile * 32 * PB;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) sv[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + s_goff[i], 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const int t_begin = blk * tiles_per_wg + wave;
+    if (t_begin < t_end) stage_load(t_begin);
+    for (int tile = t_begin; tile < t_end; tile += 4) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            if (s_loff[i] >= 0) *reinterpret_cast<u32x4*>(Lw + s_loff[i]) = sv[i];
+        if (tile + 4 < t_end) stage_load(tile + 4);
+        const int q = tile * 32 + 2 * fr;
+        const int y = (int)__umulhi((unsigned)q, magicW);
+        const int x = q - y * W;
+        const bool colok = !(fq == 0 && x == 0) && !(fq == 3 && x == W - 2);
+        const unsigned char* rb = Lw + (2 * fr + fq) * PB;
+        const unsigned char* r0 = colok ? rb : Lz;
+        const unsigned char* r1 = colok ? rb + ROWB : Lz;
+        const unsigned char* r2 = colok ? rb + 2 * ROWB : Lz;
+        const bool live = q + pp < HW;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const u32x4 x0 = *reinterpret_cast<const u32x4*>(r0 + u * 16);
+            const u32x4 x1 = *reinterpret_cast<const u32x4*>(r1 + u * 16);
+            const u32x4 x2 = *reinterpret_cast<const u32x4*>(r2 + u * 16);
+            f32x4 acc = bb[u];
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const dw_bf16x8*>(&dwf[u][0]), *reinterpret_cast<const dw_bf16x8*>(&x0), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const dw_bf16x8*>(&dwf[u][1]), *reinterpret_cast<const dw_bf16x8*>(&x1), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const dw_bf16x8*>(&dwf[u][2]), *reinterpret_cast<const dw_bf16x8*>(&x2), acc, 0, 0, 0);
+            MI355_ACT_DISPATCH(act, {
+                acc.x = act_c<ACT>(acc.x); acc.y = act_c<ACT>(acc.y); acc.z = act_c<ACT>(acc.z); acc.w = act_c<ACT>(acc.w);
+            })
+            if (live) { psum[u][0] += acc.x; psum[u][1] += acc.y; psum[u][2] += acc.z; psum[u][3] += acc.w; }
+            u32x2 o;
+            o.x = pack2bf(acc.x, acc.y);
+            o.y = pack2bf(acc.z, acc.w);
+            *reinterpret_cast<u32x2*>(Lo + (2 * fr + pp) * PB + u * 16 + ch4 * 2) = o;
+        }
+        // the tile's 32 output pixels are one contiguous run in memory
+        const int nvalid = min(32, HW - tile * 32) * PB;
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int ob_off = (lane + 64 * i) * 16;
+            if (ob_off < nvalid && ob_off < OUTB)
+                *reinterpret_cast<u32x4*>(ob + (size_t)tile * 32 * PB + ob_off) = *reinterpret_cast<const u32x4*>(Lo + ob_off);
+        }
+    }
+    if (pool_partial) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) psum[u][j] += __shfl_xor(psum[u][j], o, 64);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) psum[u][j] += __shfl_xor(psum[u][j], 32, 64);
+            if (fr == 0 && fq < 2)
+                *reinterpret_cast<f32x4*>(&red[wave][u * 8 + ch4]) = (f32x4){psum[u][0], psum[u][1], psum[u][2], psum[u][3]};
+        }
+        __syncthreads();
+        if (threadIdx.x < NU * 8)
+            pool_partial[((size_t)b * nblk + blk) * C + threadIdx.x] =
+                ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    }
+}
+
+template <int NU>
+static void launch_dw3_lds(const bf16_t* in, const bf16_t* w, const float* bias, bf16_t* out, float* pool_partial, int B, int nb,
+                           int H, int W, int act, unsigned magic, int tpw, hipStream_t st) {
+    hipLaunchKernelGGL((k_dw3_lds<NU>), dim3((unsigned)(8 * cdiv(B, 8) * nb)), dim3(256), 0, st, in, w, bias, out, pool_partial, B,
+                       nb, H, W, act, magic, tpw);
+}
+
+template <int NU>
+static void launch_dw3_mfma(const bf16_t* in, const bf16_t* w, const float* bias, bf16_t* out, float* pool_partial, int B, int nb,
+                            int H, int W, int C, int cu0, int act, unsigned magic, int tpw, hipStream_t st) {
+    hipLaunchKernelGGL((k_dw3_mfma<NU>), dim3((unsigned)(8 * cdiv(B, 8) * nb)), dim3(256), 0, st, in, w, bias, out, pool_partial, B,
+                       nb, H, W, C, cu0, act, magic, tpw);
+}
+
 int launch_dwconv(const bf16_t* in, const bf16_t* w, const float* bias, bf16_t* out, float* pool_partial, int B, int H,
                   int W, int C, int k, int stride, int act, int* pool_nblk, hipStream_t st) {
     MI355_REQUIRE(C % 8 == 0, "dwconv: C=%d must be a multiple of 8", C);
@@ -502,6 +767,43 @@ int launch_dwconv(const bf16_t* in, const bf16_t* w, const float* bias, bf16_t* 
                                    : launch_dw_tiled<3, 4>(in, w, bias, out, pool_partial, B, H, W, C, TH, CGC, lds, act, pool_nblk, st);
         return PX == 7 ? launch_dw_tiled<5, 7>(in, w, bias, out, pool_partial, B, H, W, C, TH, CGC, lds, act, pool_nblk, st)
                        : launch_dw_tiled<5, 4>(in, w, bias, out, pool_partial, B, H, W, C, TH, CGC, lds, act, pool_nblk, st);
+    }
+    // narrow 3x3 stride-1 layers: MFMA kernel (0.218 -> see DESIGN.md for C40 @112x112); MI355_DW_MFMA=0 keeps the direct kernel
+    static const int use_mfma = getenv("MI355_DW_MFMA") ? atoi(getenv("MI355_DW_MFMA")) : 1;
+    if (use_mfma && k == 3 && stride == 1 && C <= 64 && W % 2 == 0 && W >= 4 && (long)H * W * C * 2 < (1L << 30)) {
+        const int ntiles = cdiv((long)H * W, 32);
+        int nb = std::min(std::min(dw_pool_blocks(Ho, Wo, C), 14), ntiles);      // <= the squeeze-partial slot the planner sized
+        const int tpw = cdiv(ntiles, nb);
+        nb = cdiv(ntiles, tpw);
+        if (pool_nblk) *pool_nblk = nb;
+        const unsigned magic = (unsigned)((0x100000000ULL + (unsigned)W - 1) / (unsigned)W);
+        static const int use_lds = getenv("MI355_DW_MFMA_LDS") ? atoi(getenv("MI355_DW_MFMA_LDS")) : 1;
+        if (use_lds && C <= 40) {
+            switch (C / 8) {
+                case 1: launch_dw3_lds<1>(in, w, bias, out, pool_partial, B, nb, H, W, act, magic, tpw, st); break;
+                case 2: launch_dw3_lds<2>(in, w, bias, out, pool_partial, B, nb, H, W, act, magic, tpw, st); break;
+                case 3: launch_dw3_lds<3>(in, w, bias, out, pool_partial, B, nb, H, W, act, magic, tpw, st); break;
+                case 4: launch_dw3_lds<4>(in, w, bias, out, pool_partial, B, nb, H, W, act, magic, tpw, st); break;
+                default: launch_dw3_lds<5>(in, w, bias, out, pool_partial, B, nb, H, W, act, magic, tpw, st); break;
+            }
+            MI355_LAUNCH_CHECK();
+            return OK;
+        }
+        // up to 5 units (40 channels) per wave; wider layers go out as several launches over unit ranges
+        for (int cu0 = 0; cu0 < C / 8;) {
+            const int left = C / 8 - cu0;
+            const int nu = left <= 5 ? left : (left == 6 ? 3 : 4);
+            switch (nu) {
+                case 1: launch_dw3_mfma<1>(in, w, bias, out, pool_partial, B, nb, H, W, C, cu0, act, magic, tpw, st); break;
+                case 2: launch_dw3_mfma<2>(in, w, bias, out, pool_partial, B, nb, H, W, C, cu0, act, magic, tpw, st); break;
+                case 3: launch_dw3_mfma<3>(in, w, bias, out, pool_partial, B, nb, H, W, C, cu0, act, magic, tpw, st); break;
+                case 4: launch_dw3_mfma<4>(in, w, bias, out, pool_partial, B, nb, H, W, C, cu0, act, magic, tpw, st); break;
+                default: launch_dw3_mfma<5>(in, w, bias, out, pool_partial, B, nb, H, W, C, cu0, act, magic, tpw, st); break;
+            }
+            cu0 += nu;
+        }
+        MI355_LAUNCH_CHECK();
+        return OK;
     }
     if (pool_nblk) *pool_nblk = dw_pool_blocks(Ho, Wo, C);
     const int nblk = dw_pool_blocks(Ho, Wo, C);
