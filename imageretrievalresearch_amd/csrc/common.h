@@ -53,8 +53,14 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     __hip_bfloat16 h = __float2bfloat16(f);  // round-to-nearest-even
     return *reinterpret_cast<bf16_t*>(&h);
 }
+// two fp32 -> one dword of two bf16: ONE v_cvt_pk_bf16_f32.  (Written as a vector convert: the scalar form
+// f2bf(lo) | f2bf(hi) << 16 let hipcc pair the producers of lo / hi with those of another pack2bf call and then spend
+// and/shift/or-sdwa instructions re-ordering the halves - 6 VALU ops per 4 values in the VALU-bound epilogues.)
+typedef __bf16 mi355_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float mi355_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
-    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+    const mi355_bf16x2 v = __builtin_convertvector((mi355_f32x2){lo, hi}, mi355_bf16x2);
+    return *reinterpret_cast<const unsigned*>(&v);
 }
 
 // sigmoid/SiLU on the transcendental pipe: exp2 + rcp (1 ulp each), no IEEE division sequence.  Every result is

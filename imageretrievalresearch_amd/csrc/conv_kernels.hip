@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256, NU >= 5 ? 3 : (NU >= 4 ? 4 : 5)) void k_dw3_mf
 // output pixels through LDS as one contiguous 32*C*2-byte run.  No barriers: a wave only touches its own LDS region, and
 // the LDS executes one wave's instructions in order.  The next tile's loads are requested before this tile's MFMAs.
 template <int NU>
-__global__ __launch_bounds__(256, NU >= 5 ? 3 : 4) void k_dw3_lds(
+__global__ __launch_bounds__(256, NU >= 4 ? 3 : 4) void k_dw3_lds(
     const bf16_t* __restrict__ in, const bf16_t* __restrict__ w, const float* __restrict__ bias, bf16_t* __restrict__ out,
     float* __restrict__ pool_partial, int B, int nblk, int H, int W, int act, unsigned magicW, int tiles_per_wg) {
     constexpr int C = NU * 8, PB = C * 2;                 // channels (the whole layer), bytes per pixel
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256, NU >= 5 ? 3 : 4) void k_dw3_lds(
     constexpr int NCH = 3 * ROWB / 16;                    // 16-byte chunks of the three windows
     constexpr int NLD = (NCH + 63) / 64;                  // staging loads per lane
     constexpr int OUTB = 32 * PB, NOC = OUTB / 16, NST = (NOC + 63) / 64;
-    constexpr int WS = 3 * ROWB + OUTB + NU * 16;         // LDS bytes per wave: windows | output tile | zeros
+    constexpr int WS = 3 * ROWB + OUTB + NU * 16 + NU * 32;   // LDS bytes per wave: windows | output tile | zeros | bias
     __shared__ __attribute__((aligned(16))) unsigned char lds[4 * WS];
     __shared__ float red[4][NU * 8];
     const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
@@ -629,7 +629,9 @@ __global__ __launch_bounds__(256, NU >= 5 ? 3 : 4) void k_dw3_lds(
     unsigned char* Lw = lds + wave * WS;
     unsigned char* Lo = Lw + 3 * ROWB;
     unsigned char* Lz = Lo + OUTB;
+    float* Lb = reinterpret_cast<float*>(Lz + NU * 16);      // this wave's copy of the bias (an LDS read per unit is cheaper than 4*NU registers)
     if (lane < NU) *reinterpret_cast<u32x4*>(Lz + lane * 16) = (u32x4){0u, 0u, 0u, 0u};
+    if (lane < NU * 8) Lb[lane] = bias[lane];
     u32x4 dwf[NU][3];
     {
         const int pm = fr >> 3, c = fr & 7, t = fq - pm;
@@ -645,9 +647,6 @@ __global__ __launch_bounds__(256, NU >= 5 ? 3 : 4) void k_dw3_lds(
             }
     }
     const int ch4 = (fq & 1) * 4, pp = fq >> 1;
-    f32x4 bb[NU];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) bb[u] = *reinterpret_cast<const f32x4*>(bias + u * 8 + ch4);
     const bf16_t* img = in + (size_t)b * HW * C;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(img), 0, HW * PB, 0x00020000);
     unsigned char* ob = reinterpret_cast<unsigned char*>(out + (size_t)b * HW * C);
@@ -696,7 +695,7 @@ __global__ __launch_bounds__(256, NU >= 5 ? 3 : 4) void k_dw3_lds(
             const u32x4 x0 = *reinterpret_cast<const u32x4*>(r0 + u * 16);
             const u32x4 x1 = *reinterpret_cast<const u32x4*>(r1 + u * 16);
             const u32x4 x2 = *reinterpret_cast<const u32x4*>(r2 + u * 16);
-            f32x4 acc = bb[u];
+            f32x4 acc = *reinterpret_cast<const f32x4*>(Lb + u * 8 + ch4);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const dw_bf16x8*>(&dwf[u][0]), *reinterpret_cast<const dw_bf16x8*>(&x0), acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const dw_bf16x8*>(&dwf[u][1]), *reinterpret_cast<const dw_bf16x8*>(&x1), acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const dw_bf16x8*>(&dwf[u][2]), *reinterpret_cast<const dw_bf16x8*>(&x2), acc, 0, 0, 0);
@@ -752,6 +751,13 @@ static void launch_dw3_mfma(const bf16_t* in, const bf16_t* w, const float* bias
                        nb, H, W, C, cu0, act, magic, tpw);
 }
 
+// MI355_DW_MFMA_LDS=0 selects the first (direct-from-global) MFMA version, kept for comparison: it is SLOWER than the VALU kernel
+// (C64 @112x112: 0.74 vs 0.29 ms), so by default the matrix-pipe path is taken only where the LDS-staged kernel applies (C <= 40)
+static int use_lds_path() {
+    static const int v = getenv("MI355_DW_MFMA_LDS") ? atoi(getenv("MI355_DW_MFMA_LDS")) : 1;
+    return v;
+}
+
 int launch_dwconv(const bf16_t* in, const bf16_t* w, const float* bias, bf16_t* out, float* pool_partial, int B, int H,
                   int W, int C, int k, int stride, int act, int* pool_nblk, hipStream_t st) {
     MI355_REQUIRE(C % 8 == 0, "dwconv: C=%d must be a multiple of 8", C);
@@ -770,15 +776,14 @@ int launch_dwconv(const bf16_t* in, const bf16_t* w, const float* bias, bf16_t* 
     }
     // narrow 3x3 stride-1 layers: MFMA kernel (0.218 -> see DESIGN.md for C40 @112x112); MI355_DW_MFMA=0 keeps the direct kernel
     static const int use_mfma = getenv("MI355_DW_MFMA") ? atoi(getenv("MI355_DW_MFMA")) : 1;
-    if (use_mfma && k == 3 && stride == 1 && C <= 64 && W % 2 == 0 && W >= 4 && (long)H * W * C * 2 < (1L << 30)) {
+    if (use_mfma && k == 3 && stride == 1 && C <= (use_lds_path() ? 40 : 64) && W % 2 == 0 && W >= 4 && (long)H * W * C * 2 < (1L << 30)) {
         const int ntiles = cdiv((long)H * W, 32);
         int nb = std::min(std::min(dw_pool_blocks(Ho, Wo, C), 14), ntiles);      // <= the squeeze-partial slot the planner sized
         const int tpw = cdiv(ntiles, nb);
         nb = cdiv(ntiles, tpw);
         if (pool_nblk) *pool_nblk = nb;
         const unsigned magic = (unsigned)((0x100000000ULL + (unsigned)W - 1) / (unsigned)W);
-        static const int use_lds = getenv("MI355_DW_MFMA_LDS") ? atoi(getenv("MI355_DW_MFMA_LDS")) : 1;
-        if (use_lds && C <= 40) {
+        if (use_lds_path() && C <= 40) {
             switch (C / 8) {
                 case 1: launch_dw3_lds<1>(in, w, bias, out, pool_partial, B, nb, H, W, act, magic, tpw, st); break;
                 case 2: launch_dw3_lds<2>(in, w, bias, out, pool_partial, B, nb, H, W, act, magic, tpw, st); break;

@@ -32,6 +32,19 @@ __device__ __forceinline__ void sw_lds_barrier() {          // orders LDS traffi
     asm volatile("" ::: "memory");
 }
 
+typedef __bf16 sw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float sw_f32x2 __attribute__((ext_vector_type(2)));
+// four fp32 -> four bf16 (two dwords) with two v_cvt_pk_bf16_f32; written with vector converts because hipcc otherwise pairs
+// the activation's last multiply as (x,z),(y,w) and then spends six ALU ops re-ordering the halves
+__device__ __forceinline__ u32x2 sw_pack4(const f32x4 v) {
+    const sw_bf16x2 lo = __builtin_convertvector((sw_f32x2){v.x, v.y}, sw_bf16x2);
+    const sw_bf16x2 hi = __builtin_convertvector((sw_f32x2){v.z, v.w}, sw_bf16x2);
+    u32x2 o;
+    o.x = *reinterpret_cast<const unsigned*>(&lo);
+    o.y = *reinterpret_cast<const unsigned*>(&hi);
+    return o;
+}
+
 // activation: compile-time for the common case (both SiLU: EfficientNet), runtime switch otherwise (AE / AD = -1)
 template <int ACT>
 __device__ __forceinline__ float sw_act(float x, int act_runtime) {
@@ -173,7 +186,7 @@ __global__ __launch_bounds__(NW * 64, (NW * OCC + 3) / 4) void k_sweep_mbconv(co
 #pragma unroll
             for (int ks = 0; ks < KST; ++ks) wf[ks] = *reinterpret_cast<const u32x4*>(a.We + (n * a.Kp + ks * 32 + fk));
         }
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(a.be + min(ch0 + fq * 4, midp - 4));
+        f32x4 bb = *reinterpret_cast<const f32x4*>(a.be + min(ch0 + fq * 4, midp - 4));
         unsigned wd_raw[(NP + 1) / 2];                        // two tap pairs per register
         {
             const int ch = min(ch0 + fr, a.mid - 1);
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(NW * 64, (NW * OCC + 3) / 4) void k_sweep_mbconv(co
                 else wd_raw[tp >> 1] = v;
             }
         }
-        const f32x4 bdr = *reinterpret_cast<const f32x4*>(a.bd + min(ch0 + fq * 4, a.mid - 4));
+        f32x4 bdr = *reinterpret_cast<const f32x4*>(a.bd + min(ch0 + fq * 4, a.mid - 4));
         // diagonal weight fragments of the depthwise MFMAs: lane (n = lane & 15, kg = lane >> 4) holds k = kg*8 + j -> tap
         // (kg >> 1), channel (kg & 1)*8 + j of the tile: nonzero only where that channel is the lane's own n
         auto build_dwf = [&](u32x4* dwf) {
@@ -201,8 +214,22 @@ __global__ __launch_bounds__(NW * 64, (NW * OCC + 3) / 4) void k_sweep_mbconv(co
         };
         constexpr bool DWF_PER_SLAB = KS == 3;               // 20 registers for 3x3; the 52 of 5x5 are rebuilt per band
         u32x4 dwf_s[DWF_PER_SLAB ? NP : 1];
-        if constexpr (DWF_PER_SLAB) build_dwf(dwf_s);
         float psum[4] = {0.f, 0.f, 0.f, 0.f};
+        // retire the slab constants (and band -1's X fragments) HERE and pass them through an empty asm: hipcc then treats them
+        // as plain register values.  Left alone it put a vmcnt(0) in front of the first depthwise MFMA of every band (first use
+        // of the depthwise bias inside the loop), which also waited for the X fragments prefetched for the next band.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < KST; ++ks) asm volatile("" : "+v"(wf[ks]));
+        asm volatile("" : "+v"(bb));
+        asm volatile("" : "+v"(bdr));
+#pragma unroll
+        for (int i = 0; i < (NP + 1) / 2; ++i) asm volatile("" : "+v"(wd_raw[i]));
+#pragma unroll
+        for (int i = 0; i < MW1; ++i)
+#pragma unroll
+            for (int ks = 0; ks < KST; ++ks) asm volatile("" : "+v"(xa[i][ks]));
+        if constexpr (DWF_PER_SLAB) build_dwf(dwf_s);
         tick(1);
 
         for (int band = -1; band < nbands; ++band) {
@@ -228,8 +255,7 @@ __global__ __launch_bounds__(NW * 64, (NW * OCC + 3) / 4) void k_sweep_mbconv(co
                                                                               *reinterpret_cast<bf16x8*>(&xa[i][ks]), acc, 0, 0, 0);
                             acc.x = sw_act<AE>(acc.x, a.act_e); acc.y = sw_act<AE>(acc.y, a.act_e);
                             acc.z = sw_act<AE>(acc.z, a.act_e); acc.w = sw_act<AE>(acc.w, a.act_e);
-                            o.x = pack2bf(acc.x, acc.y);
-                            o.y = pack2bf(acc.z, acc.w);
+                            o = sw_pack4(acc);
                             if (t0 < plo || t0 + 16 > phi) {                     // (wave-uniform) tile straddles the image edge
                                 const bool in = t0 + fr >= plo && t0 + fr < phi;
                                 o.x = in ? o.x : 0u; o.y = in ? o.y : 0u;
@@ -295,10 +321,7 @@ __global__ __launch_bounds__(NW * 64, (NW * OCC + 3) / 4) void k_sweep_mbconv(co
                         if (p < np2) {
                             psum[0] += acc.x; psum[1] += acc.y; psum[2] += acc.z; psum[3] += acc.w;
                             if (ch0 + fq * 4 < a.mid) {
-                                u32x2 ov;
-                                ov.x = pack2bf(acc.x, acc.y);
-                                ov.y = pack2bf(acc.z, acc.w);
-                                *reinterpret_cast<u32x2*>(Dband + p * a.mid) = ov;
+                                *reinterpret_cast<u32x2*>(Dband + p * a.mid) = sw_pack4(acc);
                             }
                         }
                     }
