@@ -98,15 +98,17 @@ template <bool CONV_INPUT>
 __global__ __launch_bounds__(256) void k_stem_u8(const StemU8Args a, const float* __restrict__ w,
                                                  const float* __restrict__ bias, bf16_t* __restrict__ out, int Ho, int Wo,
                                                  int Cout, int act) {
+    // CONV_INPUT: the workgroup's 32 x 8 output pixels need conv_input + SiLU on a 65 x 17 window, which needs the
+    // pre-processed image on a 67 x 19 window.  Both windows are computed ONCE per workgroup into LDS (the first version
+    // recomputed a private 5 x 5 window and nine conv_input taps per thread: 256 VGPRs + 298 spilled, 2.65 ms per batch).
+    constexpr int PW = 67, PH = 19, CWD = 65, CHT = 17;
     __shared__ float scw[81];
-    if (CONV_INPUT) {
-        if (threadIdx.x < 81) scw[threadIdx.x] = a.cw[threadIdx.x];
-        __syncthreads();
-    }
+    __shared__ float Pt[CONV_INPUT ? PH * PW * 3 : 1];
+    __shared__ float Ct[CONV_INPUT ? CHT * CWD * 3 : 1];
     const int b = blockIdx.z;
-    const int ox = blockIdx.x * 32 + (threadIdx.x & 31);
-    const int oy = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (ox >= Wo || oy >= Ho) return;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int ox = blockIdx.x * 32 + lx;
+    const int oy = blockIdx.y * 8 + ly;
     const unsigned char* ib = a.img + (size_t)b * a.h * a.w * 3;
     // the model input at (y, x, c): 0 outside the S x S square (the convolutions' zero padding), the normalised fill
     // colour in the SquarePad border, the normalised pixel inside the image - one rounding per fp32 op, as torch does
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(256) void k_stem_u8(const StemU8Args a, const float
     };
     float p[27];
     if (!CONV_INPUT) {
+        if (ox >= Wo || oy >= Ho) return;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -126,34 +129,42 @@ __global__ __launch_bounds__(256) void k_stem_u8(const StemU8Args a, const float
 #pragma unroll
                 for (int ci = 0; ci < 3; ++ci) p[(ky * 3 + kx) * 3 + ci] = pre(oy * 2 - 1 + ky, ox * 2 - 1 + kx, ci);
     } else {
-        // 5x5 window of the pre-processed image around the stem's 3x3 taps, then conv_input + SiLU at the nine taps
-        float q[5][5][3];
+        if (threadIdx.x < 81) scw[threadIdx.x] = a.cw[threadIdx.x];
+        const int y0 = blockIdx.y * 16 - 2, x0 = blockIdx.x * 64 - 2;      // pre-processed window origin
+        for (int i = threadIdx.x; i < PH * PW; i += 256) {
+            const int r = i / PW, c = i - r * PW;
 #pragma unroll
-        for (int dy = 0; dy < 5; ++dy)
+            for (int ci = 0; ci < 3; ++ci) Pt[i * 3 + ci] = pre(y0 + r, x0 + c, ci);
+        }
+        __syncthreads();
+        // conv_input + SiLU on the window the stem taps touch (origin y0 + 1, x0 + 1); same (ci, ky, kx) order as
+        // k_conv_input_silu; positions outside the S x S square are the stem's zero padding
+        for (int i = threadIdx.x; i < CHT * CWD; i += 256) {
+            const int r = i / CWD, c = i - r * CWD;
+            const int y = y0 + 1 + r, x = x0 + 1 + c;
+            float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-            for (int dx = 0; dx < 5; ++dx)
+            for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
-                for (int ci = 0; ci < 3; ++ci) q[dy][dx][ci] = pre(oy * 2 - 2 + dy, ox * 2 - 2 + dx, ci);
+                for (int ky2 = 0; ky2 < 3; ++ky2)
+#pragma unroll
+                    for (int kx2 = 0; kx2 < 3; ++kx2) {
+                        const float v = Pt[((r + ky2) * PW + c + kx2) * 3 + ci];
+#pragma unroll
+                        for (int co = 0; co < 3; ++co) acc[co] += v * scw[((co * 3 + ci) * 3 + ky2) * 3 + kx2];
+                    }
+            const bool in = y >= 0 && y < a.S && x >= 0 && x < a.S;
+#pragma unroll
+            for (int co = 0; co < 3; ++co) Ct[i * 3 + co] = in ? silu_f(acc[co]) : 0.f;
+        }
+        __syncthreads();
+        if (ox >= Wo || oy >= Ho) return;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int y = oy * 2 - 1 + ky, x = ox * 2 - 1 + kx;
-                float acc[3] = {0.f, 0.f, 0.f};
+            for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                for (int ci = 0; ci < 3; ++ci)            // same (ci, ky, kx) order as k_conv_input_silu
-#pragma unroll
-                    for (int ky2 = 0; ky2 < 3; ++ky2)
-#pragma unroll
-                        for (int kx2 = 0; kx2 < 3; ++kx2) {
-                            const float v = q[ky + ky2][kx + kx2][ci];
-#pragma unroll
-                            for (int co = 0; co < 3; ++co) acc[co] += v * scw[((co * 3 + ci) * 3 + ky2) * 3 + kx2];
-                        }
-                const bool in = y >= 0 && y < a.S && x >= 0 && x < a.S;   // outside: the stem's zero padding
-#pragma unroll
-                for (int co = 0; co < 3; ++co) p[(ky * 3 + kx) * 3 + co] = in ? silu_f(acc[co]) : 0.f;
-            }
+                for (int co = 0; co < 3; ++co) p[(ky * 3 + kx) * 3 + co] = Ct[((ly * 2 + ky) * CWD + lx * 2 + kx) * 3 + co];
     }
     bf16_t* o = out + (((size_t)b * Ho + oy) * Wo + ox) * Cout;
     for (int c0 = 0; c0 < Cout; c0 += 8) {

@@ -24,5 +24,8 @@ for name, e in sorted(agg.items()):
     derived(o)
     if "FETCH_SIZE" in o:
         o["fetch_bytes_corrected"] = 2.0 * o["FETCH_SIZE"] * 1024.0
+    if "WRITE_SIZE" in o:
+        o["write_bytes"] = o["WRITE_SIZE"] * 1024.0
+        o["hbm_bytes_per_launch"] = o.get("fetch_bytes_corrected", 0.0) + o["write_bytes"]
     out[name] = o
 print(json.dumps(out, indent=1))

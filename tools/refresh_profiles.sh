@@ -19,6 +19,8 @@ python tools/bench_models.py > $OUT/${R}_bench_models.txt 2>&1
 python tools/bench_rank.py > $OUT/${R}_bench_rank.txt 2>&1
 python tools/bench_latency.py > $OUT/${R}_bench_latency.txt 2>&1
 python tools/check_block.py > $OUT/${R}_block_kernel_phases.txt 2>&1
+python tools/tune_sweep.py 0 0 0 stamps > $OUT/${R}_sweep_kernel_phases.txt 2>&1
+python tools/bench_small_batch.py > $OUT/${R}_bench_small_batch.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/bench_prof.err
 rocprofv3 -L > $OUT/counters_list.txt 2>&1
@@ -37,4 +39,14 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_rank_fetch -- python3
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_rank_sq -- python3 $ROOT/tools/bench_rank.py > $OUT/pmc_rank_sq.log 2>&1
 cd $ROOT
 python tools/pmc_kernels.py $OUT/pmc_rank_fetch $OUT/pmc_rank_sq > $OUT/${R}_pmc_rank_kernels.json 2> $OUT/pmc_rank.err
+# RexNet-200 and Swin-B: HBM traffic + pipe busy per kernel name
+cd /tmp
+for m in "rexnet_200 256 rexnet200" "swin_base_patch4_window7_224 128 swin_base"; do
+  set -- $m
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_$3_fetch -- python3 $ROOT/tools/pmc_run.py $1 $2 > $OUT/pmc_$3_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_$3_write -- python3 $ROOT/tools/pmc_run.py $1 $2 > $OUT/pmc_$3_write.log 2>&1
+  rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d $OUT/pmc_$3_sq -- python3 $ROOT/tools/pmc_run.py $1 $2 > $OUT/pmc_$3_sq.log 2>&1
+  (cd $ROOT && python tools/pmc_kernels.py $OUT/pmc_$3_fetch $OUT/pmc_$3_write $OUT/pmc_$3_sq > $OUT/${R}_pmc_$3_kernels.json 2>> $OUT/pmc_rank.err)
+done
+cd $ROOT
 ls $OUT/${R}_*
