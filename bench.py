@@ -213,11 +213,15 @@ def main():
                 groups[-1][3] += by                    # an op executed inside the previous launch
                 groups[-1][4] += 1
         top = max(groups, key=lambda g: g[2])
-        kernel_of = {1: {"gemm": "k_gemm_bf16 / k_gemm_big / k_gemm_stream (1x1 conv)", "dw": "k_dwconv", "stem": "k_stem",
+        kernel_of = {1: {"gemm": "k_gemm_bf16 / k_gemm_big / k_gemm_stream (1x1 conv)", "dw": "k_dwconv / k_dw3_lds", "stem": "k_stem",
                          "se": "k_se", "attn": "k_win_attn", "ln": "k_layernorm", "other": "other"},
-                     2: "k_fused_late / k_fused_band (1x1 expand + depthwise + SE squeeze, expanded tensor in LDS)",
+                     2: "k_fused_late (1x1 expand + depthwise + SE squeeze on a whole-image tile, expanded tensor in LDS)",
                      4: "k_mbconv_block (whole MBConv block: expand, MFMA depthwise, SE, gated projection, residual)"}
-        kname = kernel_of[top[4]] if top[4] > 1 else kernel_of[1].get(top[1], top[1])
+        if top[4] == 2 and any(t in top[0] for t in ("@112x112", "@56x56", "@28x28")):
+            kname = ("k_sweep_mbconv (row sweep: 1x1 expand on MFMA + depthwise on MFMA from an LDS row window + SE squeeze; the "
+                     "expanded tensor never reaches HBM, so the layer-granular bytes below exceed what the launch moves)")
+        else:
+            kname = kernel_of[top[4]] if top[4] > 1 else kernel_of[1].get(top[1], top[1])
         achieved = top[3] / (top[2] * 1e-3) / 1e9
         # HBM bytes of that launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs, gfx950
         # x2 read correction) - cannot be collected from inside this process; null when the summary is from other code
