@@ -17,8 +17,8 @@ import glob
 import json
 import os
 
-OP_KERNELS = ("k_stem", "k_gemm", "k_dwconv", "k_dw_tiled", "k_se", "k_fused", "k_mbconv_block", "k_win_attn", "k_layernorm",
-              "k_patch_embed", "k_ln_token_mean")
+OP_KERNELS = ("k_stem", "k_gemm", "k_dwconv", "k_dw_tiled", "k_dw3_", "k_se", "k_fused", "k_mbconv_block", "k_sweep_mbconv",
+              "k_win_attn", "k_layernorm", "k_patch_embed", "k_ln_token_mean")
 
 
 def family(name: str) -> str:
@@ -26,9 +26,11 @@ def family(name: str) -> str:
         return "gemm"
     if "k_mbconv_block" in name:
         return "block"
+    if "k_sweep_mbconv" in name:
+        return "sweep"
     if "k_fused" in name:
         return "fused"
-    if "k_dwconv" in name or "k_dw_tiled" in name:
+    if "k_dwconv" in name or "k_dw_tiled" in name or "k_dw3_" in name:
         return "dw"
     if "k_se" in name:
         return "se"
