@@ -473,6 +473,9 @@ _Pragma("unroll")
                 for (int q = 0; q < 4; ++q)
                     w[it][q] = *reinterpret_cast<const u32x4*>(a.W1 + (min(j0 + q, a.rd - 1) * a.mid + c8 * 8));
             }
+            float b1v[4];                                      // requested with the weights: as a load behind the reduction it was
+#pragma unroll                                             // one more exposed L2 round trip per pass
+            for (int q = 0; q < 4; ++q) b1v[q] = a.b1[min(j0 + q, a.rd - 1)];
             __builtin_amdgcn_sched_barrier(0);
             float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -491,7 +494,7 @@ _Pragma("unroll")
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float t = wave_sum(s[q]);
-                if (lane == 0 && j0 + q < a.rd) rvec[j0 + q] = apply_act(t * a.inv_hw + a.b1[j0 + q], a.se_act);
+                if (lane == 0 && j0 + q < a.rd) rvec[j0 + q] = apply_act(t * a.inv_hw + b1v[q], a.se_act);
             }
         }
     }
@@ -504,22 +507,42 @@ _Pragma("unroll")
         if (JS > 8) JS = 8;
         if (JS < 1) JS = 1;
         float* part = reinterpret_cast<float*>(R);           // [JS][mid]
+        // the gate's bias, requested before anything else of this phase: as a load inside the reduction loop below it waited (vmcnt
+        // is in order) for the whole first A chunk of the projection that is requested in between
+        float b2v[5];                                        // mid <= 2560 (host check): <= 5 channels per thread
+#pragma unroll
+        for (int i = 0; i < 5; ++i) b2v[i] = a.b2[min(tid + i * MB_THREADS, a.mid - 1)];
         for (int ch0 = tid % nch + (tid / nch >= JS ? nch : 0); ch0 < nch; ch0 += (JS == 1 ? MB_THREADS : nch)) {
             const int ch = (ch0 + rb2 * 7) % nch;              // channel chunks rotated by image (L2 spreading)
             const int js = JS == 1 ? 0 : tid / nch;
             float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 12
-            for (int j = js; j < a.rd; j += JS) {
-                const u32x4 w = *reinterpret_cast<const u32x4*>(a.W2 + (j * a.mid + ch * 8));
-                const float r = rvec[j];
-                s[0] += mb_lo(w.x) * r; s[1] += mb_hi(w.x) * r; s[2] += mb_lo(w.y) * r; s[3] += mb_hi(w.y) * r;
-                s[4] += mb_lo(w.z) * r; s[5] += mb_hi(w.z) * r; s[6] += mb_lo(w.w) * r; s[7] += mb_hi(w.w) * r;
+            // batches of NBJ loads, all requested before the first multiply (a `#pragma unroll 12` over the runtime trip count put
+            // every iteration of short loops into the one-at-a-time remainder loop: a dependent L2 round trip per hidden unit);
+            // slots past rd re-read the last row and multiply by zero - the order of the real terms is unchanged
+            constexpr int NBJ = 16;
+            for (int jb = js; jb < a.rd; jb += JS * NBJ) {
+                u32x4 w[NBJ];
+                float r[NBJ];
+#pragma unroll
+                for (int t = 0; t < NBJ; ++t) {
+                    const int j = jb + t * JS;
+                    w[t] = *reinterpret_cast<const u32x4*>(a.W2 + (min(j, a.rd - 1) * a.mid + ch * 8));
+                    r[t] = j < a.rd ? rvec[j] : 0.f;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NBJ; ++t) {
+                    s[0] += mb_lo(w[t].x) * r[t]; s[1] += mb_hi(w[t].x) * r[t]; s[2] += mb_lo(w[t].y) * r[t]; s[3] += mb_hi(w[t].y) * r[t];
+                    s[4] += mb_lo(w[t].z) * r[t]; s[5] += mb_hi(w[t].z) * r[t]; s[6] += mb_lo(w[t].w) * r[t]; s[7] += mb_hi(w[t].w) * r[t];
+                }
             }
             *reinterpret_cast<f32x4*>(&part[js * a.mid + ch * 8]) = (f32x4){s[0], s[1], s[2], s[3]};
             *reinterpret_cast<f32x4*>(&part[js * a.mid + ch * 8 + 4]) = (f32x4){s[4], s[5], s[6], s[7]};
             if (JS > 1) break;
         }
+        tick(10);
         mb_lds_barrier();
+        tick(11);
         // chunk 0 of the projection operands is requested here: it travels while the gate is reduced and the A buffers zeroed
         a_load(0);
 #pragma unroll
@@ -528,18 +551,23 @@ _Pragma("unroll")
         // the gate goes to the START of the LDS (the X image is dead: the residual is re-read from L2), so that the
         // projection's A double buffer can take everything behind it
         float* gate_w = reinterpret_cast<float*>(mb_smem);
-        for (int c = tid; c < ((a.mid + 255) & ~255); c += MB_THREADS) {
+        tick(12);
+#pragma unroll
+        for (int ci = 0; ci < 5; ++ci) {
+            const int c = tid + ci * MB_THREADS;
+            if (c >= ((a.mid + 255) & ~255)) break;
             float g = 0.f;                                   // K tail of the last projection chunk: gate 0
             if (c < a.mid) {
-                g = a.b2[c];
+                g = b2v[ci];
                 for (int js = 0; js < JS; ++js) g += part[js * a.mid + c];
                 g = sigmoid_f(g);
             }
             gate_w[c] = g;
         }
+        tick(13);
         mb_lds_barrier();
     }
-    tick(10);
+    tick(14);
 
     {
         f32x4 acc[NTW][MWP];
@@ -559,7 +587,7 @@ _Pragma("unroll")
         mb_lds_barrier();
         // One wait point per iteration (the a_store at the top, vmcnt(0)): everything it waits for was requested at least
         // an MFMA phase earlier.
-        tick(11);
+        tick(15);
         for (int ch = 0; ch < nchunks; ++ch) {
             if (ch + 1 < nchunks) a_store(ch + 1);     // chunk ch+1: registers -> gated bf16 -> the other LDS buffer (vmcnt(0))
             // every loop-carried register is "read" HERE, right behind the wait (an empty asm that takes and returns it):
@@ -572,7 +600,7 @@ _Pragma("unroll")
             __builtin_amdgcn_sched_barrier(0);
             if (ch + 2 < nchunks) a_load(ch + 2);      // chunk ch+2's rows travel during this chunk's MFMAs
             __builtin_amdgcn_sched_barrier(0);
-            tick(12);
+            tick(15);
             const bf16_t* as = As + (ch & 1) * abuf;
             // A fragments of a k-step as one batch, one k-step ahead of the MFMAs (row tiles past the end are clamped: their
             // results are never stored)
@@ -608,9 +636,9 @@ _Pragma("unroll")
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            tick(13);
+            tick(15);
             mb_lds_barrier();
-            tick(14);
+            tick(15);
         }
         // epilogue: lane holds 4 consecutive output channels of one pixel; the residual comes back from L2 (all loads
         // requested before the first use)
