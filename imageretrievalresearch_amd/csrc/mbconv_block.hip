@@ -540,9 +540,7 @@ _Pragma("unroll")
             *reinterpret_cast<f32x4*>(&part[js * a.mid + ch * 8 + 4]) = (f32x4){s[4], s[5], s[6], s[7]};
             if (JS > 1) break;
         }
-        tick(10);
         mb_lds_barrier();
-        tick(11);
         // chunk 0 of the projection operands is requested here: it travels while the gate is reduced and the A buffers zeroed
         a_load(0);
 #pragma unroll
@@ -551,7 +549,6 @@ _Pragma("unroll")
         // the gate goes to the START of the LDS (the X image is dead: the residual is re-read from L2), so that the
         // projection's A double buffer can take everything behind it
         float* gate_w = reinterpret_cast<float*>(mb_smem);
-        tick(12);
 #pragma unroll
         for (int ci = 0; ci < 5; ++ci) {
             const int c = tid + ci * MB_THREADS;
@@ -564,10 +561,9 @@ _Pragma("unroll")
             }
             gate_w[c] = g;
         }
-        tick(13);
         mb_lds_barrier();
     }
-    tick(14);
+    tick(10);
 
     {
         f32x4 acc[NTW][MWP];
@@ -587,7 +583,7 @@ _Pragma("unroll")
         mb_lds_barrier();
         // One wait point per iteration (the a_store at the top, vmcnt(0)): everything it waits for was requested at least
         // an MFMA phase earlier.
-        tick(15);
+        tick(11);
         for (int ch = 0; ch < nchunks; ++ch) {
             if (ch + 1 < nchunks) a_store(ch + 1);     // chunk ch+1: registers -> gated bf16 -> the other LDS buffer (vmcnt(0))
             // every loop-carried register is "read" HERE, right behind the wait (an empty asm that takes and returns it):
@@ -600,7 +596,7 @@ _Pragma("unroll")
             __builtin_amdgcn_sched_barrier(0);
             if (ch + 2 < nchunks) a_load(ch + 2);      // chunk ch+2's rows travel during this chunk's MFMAs
             __builtin_amdgcn_sched_barrier(0);
-            tick(15);
+            tick(12);
             const bf16_t* as = As + (ch & 1) * abuf;
             // A fragments of a k-step as one batch, one k-step ahead of the MFMAs (row tiles past the end are clamped: their
             // results are never stored)
@@ -636,9 +632,9 @@ _Pragma("unroll")
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            tick(15);
+            tick(13);
             mb_lds_barrier();
-            tick(15);
+            tick(14);
         }
         // epilogue: lane holds 4 consecutive output channels of one pixel; the residual comes back from L2 (all loads
         // requested before the first use)
