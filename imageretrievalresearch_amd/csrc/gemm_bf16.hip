@@ -674,6 +674,169 @@ static int launch_stream_cfg(const GemmArgs& a, hipStream_t st) {
     return OK;
 }
 
+// =====================================================================================
+// Narrow-output projections (N <= 48, K <= 288: the SE-gated 1x1 projections of the 112x112 .. 28x28 blocks).  The tiled
+// kernel ran them at 3.4-4.1 TB/s with its waves waiting 70-80 % of the time (load -> barrier -> store per 32-deep
+// k-step).  Here a wave owns 16 consecutive rows (one contiguous 16*K*2-byte run of A): it copies them with contiguous
+// 16-byte loads into its PRIVATE LDS strip - applying the SE gate / ReLU6 on the way, same rounding point bf16(A * g) as
+// gate_chunk - multiplies against W resident in LDS, and writes its 16 x N outputs back as one contiguous run.  No
+// workgroup barrier after the prologue; the next tile's loads are requested before this tile's MFMAs.  (Same structure
+// as k_dw3_lds, which took the narrow depthwise layers from 2.4 to 4.0 TB/s.)
+// =====================================================================================
+template <int NT, int KST>
+__global__ __launch_bounds__(512) void k_proj_lds(const GemmArgs g) {
+    constexpr int NW = 8;
+    constexpr int KP = KST * 32;                           // padded K
+    constexpr int WLD = KP + 8, ALD = KP + 8, CLD = NT * 16 + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+    bf16_t* Wsh = reinterpret_cast<bf16_t*>(psm);                                   // [NT*16][WLD]
+    float* sbias = reinterpret_cast<float*>(psm + (size_t)NT * 16 * WLD * 2);       // [NT*16]
+    unsigned char* wbase = psm + (size_t)NT * 16 * WLD * 2 + NT * 16 * 4;
+    constexpr int WS = 16 * ALD * 2 + 16 * CLD * 2 + KP * 4;                        // per wave: A strip | C strip | gate
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    bf16_t* As = reinterpret_cast<bf16_t*>(wbase + (size_t)wave * WS);
+    bf16_t* Cs = As + 16 * ALD;
+    float* Gs = reinterpret_cast<float*>(Cs + 16 * CLD);
+    const int Npad = (g.N + 15) & ~15;
+    for (int id = tid; id < NT * 16 * KST * 4; id += 512) {
+        const int row = id / (KST * 4), c = id - row * (KST * 4);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < Npad && c * 8 < g.ldw) v = *reinterpret_cast<const u32x4*>(g.W + (size_t)row * g.ldw + c * 8);
+        *reinterpret_cast<u32x4*>(&Wsh[row * WLD + c * 8]) = v;
+    }
+    for (int n = tid; n < NT * 16; n += 512) sbias[n] = n < Npad ? g.bias[n] : 0.f;
+    // the strip's columns K .. KP stay zero (A is only written for k < K)
+    for (int id = lane; id < 16 * (ALD / 8); id += 64) *reinterpret_cast<u32x4*>(&As[id * 8]) = (u32x4){0u, 0u, 0u, 0u};
+    __syncthreads();
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int kc = g.K >> 3;                               // 16-byte chunks per row
+    const int nchunk = 16 * kc;                            // chunks of a 16-row tile (contiguous in memory when lda == K)
+    const int ntiles = (g.M + 15) >> 4;
+    const int stride = gridDim.x * NW;
+    int img = -1;
+    u32x4 sv[KST];
+    auto stage_load = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < KST; ++i) {
+            const int id = min(lane + 64 * i, nchunk - 1);
+            const int row = id / kc, c = id - row * kc;
+            const int m = min(tile * 16 + row, g.M - 1);   // clamped: rows past M are never stored
+            sv[i] = *reinterpret_cast<const u32x4*>(g.A + (size_t)m * g.lda + c * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int tile = blockIdx.x * NW + wave;
+    if (tile < ntiles) stage_load(tile);
+    for (; tile < ntiles; tile += stride) {
+        if (g.gate) {
+            const int im = (tile * 16) / g.rows_per_img;   // (host: rows_per_img % 16 == 0, a tile lies in one image)
+            if (im != img) {
+                img = im;
+                for (int k4 = lane; k4 * 4 < g.K; k4 += 64)
+                    *reinterpret_cast<f32x4*>(&Gs[k4 * 4]) = *reinterpret_cast<const f32x4*>(g.gate + (size_t)im * g.gate_ld + k4 * 4);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < KST; ++i) {
+            const int id = lane + 64 * i;
+            if (id < nchunk) {
+                const int row = id / kc, c = id - row * kc;
+                u32x4 v = sv[i];
+                if (g.gate) v = gate_chunk(v, Gs + c * 8, g.a_relu6);
+                else if (g.a_relu6) v = relu6_chunk(v);
+                *reinterpret_cast<u32x4*>(&As[row * ALD + c * 8]) = v;
+            }
+        }
+        if (tile + stride < ntiles) stage_load(tile + stride);
+        // accumulate from zero and add the bias afterwards, k-steps in ascending order: bit-identical to k_gemm_bf16, so which
+        // of the two kernels a batch size selects never shows in the result (tests: batch-neighbour invariance)
+        f32x4 acc[NT];
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) acc[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KST; ++ks) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(&As[fr * ALD + ks * 32 + fq * 8]);
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(&Wsh[(ni * 16 + fr) * WLD + ks * 32 + fq * 8]);
+                acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[ni], 0, 0, 0);
+            }
+        }
+        MI355_ACT_DISPATCH(g.act, {
+_Pragma("unroll")
+            for (int ni = 0; ni < NT; ++ni) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(&sbias[ni * 16 + fq * 4]);
+                acc[ni].x = act_c<ACT>(acc[ni].x + bb.x); acc[ni].y = act_c<ACT>(acc[ni].y + bb.y);
+                acc[ni].z = act_c<ACT>(acc[ni].z + bb.z); acc[ni].w = act_c<ACT>(acc[ni].w + bb.w);
+            }
+        })
+        const int m = tile * 16 + fr;
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+            const int n = ni * 16 + fq * 4;
+            float v[4] = {acc[ni].x, acc[ni].y, acc[ni].z, acc[ni].w};
+            if (g.res && m < g.M && n < g.N) {
+                if (n + 3 < g.res_n) {
+                    const u32x2 rr = *reinterpret_cast<const u32x2*>(g.res + (size_t)m * g.ldr + n);
+                    v[0] += lo_bf(rr.x); v[1] += hi_bf(rr.x); v[2] += lo_bf(rr.y); v[3] += hi_bf(rr.y);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < g.res_n) v[r] += bf2f(g.res[(size_t)m * g.ldr + n + r]);
+                }
+            }
+            u32x2 o;
+            o.x = pack2bf(v[0], v[1]);
+            o.y = pack2bf(v[2], v[3]);
+            *reinterpret_cast<u32x2*>(&Cs[fr * CLD + n]) = o;
+        }
+        // (same wave wrote and reads: LDS ops complete in order, no barrier needed)
+        constexpr int CPR = NT * 2;               // 16-byte chunks per row (padded width)
+#pragma unroll
+        for (int i = 0; i < (16 * CPR + 63) / 64; ++i) {
+            const int id = lane + 64 * i;
+            const int row = id / CPR, c = id - row * CPR;
+            const int mm = tile * 16 + row;
+            if (id < 16 * CPR && mm < g.M && c * 8 < g.N)
+                *reinterpret_cast<u32x4*>((bf16_t*)g.out + (size_t)mm * g.ldo + c * 8) =
+                    *reinterpret_cast<const u32x4*>(&Cs[row * CLD + c * 8]);
+        }
+    }
+}
+
+template <int NT, int KST>
+static int launch_proj_cfg(const GemmArgs& a, hipStream_t st) {
+    constexpr int KP = KST * 32;
+    const size_t lds = (size_t)NT * 16 * (KP + 8) * 2 + (size_t)NT * 16 * 4 +
+                       (size_t)8 * (16 * (KP + 8) * 2 + 16 * (NT * 16 + 8) * 2 + KP * 4);
+    static bool attr_done[MI355_MAX_DEVICES] = {false};   // per device
+    if (first_time_on_this_device(attr_done)) {
+        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_proj_lds<NT, KST>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            160 * 1024));
+    }
+    const int ntiles = cdiv(a.M, 16);
+    int blocks = cdiv(ntiles, 8);
+    if (blocks > 256 * 6) blocks = 256 * 6;     // a few workgroups per CU, each streaming many tiles
+    hipLaunchKernelGGL((k_proj_lds<NT, KST>), dim3(blocks), dim3(512), lds, st, a);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
+// -1 = shape not covered
+static int try_launch_proj(const GemmArgs& a, hipStream_t st) {
+    // measured (EfficientNet-B3a B=256): 112x112 / 56x56 projections 0.111 -> 0.087, 0.135 -> 0.108, 0.082 -> 0.058, 0.105 -> 0.096 ms;
+    // the 28x28 ones (M = 200k rows, K = 192 / 288: one workgroup per CU) lose 0.030 -> 0.039, 0.044 -> 0.057: large M only
+    if (a.out_f32 || a.M < (1 << 19) || a.N % 8 || a.ldo % 8 || a.N > 48 || a.K > 288 || a.lda != a.K) return -1;
+    if (a.gate && (a.rows_per_img % 16 != 0 || a.gate_ld % 4 != 0)) return -1;
+    const int kst = (a.K + 31) / 32, nt = (a.N + 15) / 16;
+#define PROJ_CASE(NTV, KSTV) if (nt == NTV && kst == KSTV) return launch_proj_cfg<NTV, KSTV>(a, st)
+    PROJ_CASE(2, 1); PROJ_CASE(2, 2); PROJ_CASE(2, 5); PROJ_CASE(2, 6); PROJ_CASE(3, 6); PROJ_CASE(3, 9); PROJ_CASE(2, 9);
+#undef PROJ_CASE
+    return -1;
+}
+
 // returns -1 when the shape is not covered (caller falls back to the tiled kernel).
 // Measured per layer (profiles/r01_effnet_per_op.txt, tools/gemm_sweep.py): streaming wins where the output row is wide and
 // K is ONE k-step: 24->144 @112x112 0.375 -> 0.284 ms, 32->192 @56x56 0.129 -> 0.107 ms (once the bias moved from 48
@@ -763,6 +926,11 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t st) {
     static const int use_stream = getenv("MI355_GEMM_STREAM") ? atoi(getenv("MI355_GEMM_STREAM")) : 1;
     if (use_stream) {
         const int e = try_launch_stream(a, st);
+        if (e >= 0) return e;
+    }
+    static const int use_proj = getenv("MI355_GEMM_PROJ") ? atoi(getenv("MI355_GEMM_PROJ")) : 1;
+    if (use_proj) {
+        const int e = try_launch_proj(a, st);
         if (e >= 0) return e;
     }
     // (measured, tools/gemm_sweep.py: N=192,K=32 runs 172 us as one 192-wide tile, 133 us as three 64-wide tiles;
