@@ -77,6 +77,9 @@ static int get_coeffs(int in_size, int out_size, hipStream_t st, const ResizeCoe
         it = g_rs_cache.emplace(key, std::move(rc)).first;
         MI355_CHECK_HIP(hipMemcpyAsync(it->second.dev, it->second.host.data(), it->second.host.size() * sizeof(int),
                                        hipMemcpyHostToDevice, st));
+        // one-time upload: finish it before the table is published, so that a later caller on ANOTHER stream never
+        // reads a table whose copy is still queued behind the first caller's stream
+        MI355_CHECK_HIP(hipStreamSynchronize(st));
     }
     *out = &it->second;
     return OK;
