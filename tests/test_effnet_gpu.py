@@ -275,6 +275,25 @@ def test_sweep_kernel_agrees_with_the_unfused_pair(setup):
         assert torch.equal(out[0], out[i]), i
 
 
+def test_projection_kernel_choice_does_not_show_in_the_result(setup):
+    """The narrow SE-gated projections run in the wave-private streaming kernel (k_proj_lds) once M = B*h*w >= 2^19 rows
+    and in the tiled kernel below that; both accumulate the k-steps in ascending order from zero and add the bias last,
+    so the block output for an image must be BIT-identical whichever kernel its batch size selects (block 1.1: 56x56,
+    192 -> 32 gated + residual; block 0.1: 112x112, 24 -> 24 gated + residual)."""
+    _, model = setup
+    model.enable_taps(True)
+    for prev, cur, c, hw in (("blocks.1.0", "blocks.1.1", 32, 56), ("blocks.0.0", "blocks.0.1", 24, 112)):
+        big = torch.from_numpy(synth.normal(31, (8, c, hw, hw)).astype(np.float32)).to(DEV).bfloat16().float()
+        model.run_between_taps(prev, cur, big)                               # M = 8*hw*hw < 2^19: tiled kernel
+        want = model.read_tap(cur).clone()
+        rep = big.repeat(32, 1, 1, 1).contiguous()                           # 256 images: streaming kernel
+        model.run_between_taps(prev, cur, rep)
+        got = model.read_tap(cur)
+        assert torch.equal(got[:8], want) and torch.equal(got[-8:], want), cur
+        del rep, got
+    model.enable_taps(False)
+
+
 TOL_BLOCK_ISOLATED = 1.5e-3   # measured <= 6e-4: a fraction of one bf16 ulp (2^-8 = 3.9e-3) of relative L2 for ONE block fed the oracle's own input
 
 
