@@ -851,6 +851,133 @@ static int try_launch_stream(const GemmArgs& a, hipStream_t st) {
     return -1;
 }
 
+// =====================================================================================
+// Split-K for tiny-M, deep-K projections (the SE-gated 1x1 projections of the 14x14 / 7x7 blocks at small batch: M = 49
+// .. a few thousand rows, K = 576 .. 2304).  The tiled kernels give such a layer 1-30 workgroups, each walking K serially
+// (one L2 round trip per 32- or 64-deep step: 30-68 us at B = 1).  Here the grid is (column tile, row tile, K chunk of
+// 256): a workgroup requests its whole 64 x 256 A chunk (gate / ReLU6 applied on the way, same rounding as gate_chunk)
+// and its 64 x 256 W chunk at once - ONE round trip - multiplies them from LDS and writes an fp32 partial tile; a second
+// kernel adds the partials in ascending chunk order, then bias, activation and residual.  Deterministic, and the chunking
+// depends on the layer only, so an image's result does not depend on its batch position or (below the M cap) batch size.
+// =====================================================================================
+constexpr int SK_KC = 256, SK_BM = 64, SK_BN = 64, SK_LD = SK_KC + 8;
+constexpr long SK_MAX_M = 4096;
+
+int gemm_splitk_chunks(long M, int rows_per_img, int N, int K) {
+    if (M > SK_MAX_M || rows_per_img > 196 || K < 512 || N < 64 || N % 8) return 0;
+    return (K + SK_KC - 1) / SK_KC;
+}
+size_t gemm_splitk_bytes(long M, int N, int K) {
+    return (size_t)((K + SK_KC - 1) / SK_KC) * (size_t)M * (size_t)((N + 15) & ~15) * sizeof(float);
+}
+
+__global__ __launch_bounds__(256) void k_gemm_splitk(const GemmArgs g, float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t sksm[];
+    bf16_t* As = sksm;                         // [64][SK_LD]
+    bf16_t* Ws = sksm + SK_BM * SK_LD;         // [64][SK_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * SK_BN, m0 = blockIdx.y * SK_BM, k0 = blockIdx.z * SK_KC;
+    const int Npad = (g.N + 15) & ~15;
+    u32x4 ra[8], rw[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                           // all 16 loads of the thread first: one round trip
+        const int id = tid + 256 * i;
+        const int row = id >> 5, c = id & 31;
+        const int k = k0 + c * 8;
+        const int m = min(m0 + row, g.M - 1), kk = min(k, g.K - 8);
+        ra[i] = *reinterpret_cast<const u32x4*>(g.A + (size_t)m * g.lda + kk);
+        const int n = min(n0 + row, Npad - 1), kw = min(k, g.ldw - 8);
+        rw[i] = *reinterpret_cast<const u32x4*>(g.W + (size_t)n * g.ldw + kw);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int id = tid + 256 * i;
+        const int row = id >> 5, c = id & 31;
+        const int k = k0 + c * 8;
+        u32x4 v = ra[i];
+        if (m0 + row < g.M && k < g.K) {
+            if (g.gate) v = gate_chunk(v, g.gate + (size_t)((m0 + row) / g.rows_per_img) * g.gate_ld + k, g.a_relu6);
+            else if (g.a_relu6) v = relu6_chunk(v);
+        } else {
+            v = (u32x4){0u, 0u, 0u, 0u};
+        }
+        *reinterpret_cast<u32x4*>(&As[row * SK_LD + c * 8]) = v;
+        u32x4 w = rw[i];
+        if (n0 + row >= Npad || k >= g.ldw) w = (u32x4){0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(&Ws[row * SK_LD + c * 8]) = w;
+    }
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < SK_KC / 32; ++ks) {
+        bf16x8 af[2], wf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * 32 + i * 16 + fr) * SK_LD + ks * 32 + fq * 8]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(&Ws[(wn * 32 + j * 16 + fr) * SK_LD + ks * 32 + fq * 8]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+    }
+    float* wsk = ws + (size_t)blockIdx.z * g.M * Npad;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 32 + i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 32 + j * 16 + fq * 4;
+            if (m < g.M && n < Npad) *reinterpret_cast<f32x4*>(wsk + (size_t)m * Npad + n) = acc[j][i];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_splitk_reduce(const GemmArgs g, const float* __restrict__ ws, int nchunks) {
+    const int Npad = (g.N + 15) & ~15, n4s = Npad >> 2;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)g.M * n4s) return;
+    const int m = (int)(t / n4s), n = (int)(t - (long)m * n4s) * 4;
+    if (n >= g.N) return;
+    f32x4 s = *reinterpret_cast<const f32x4*>(ws + (size_t)m * Npad + n);
+    for (int c = 1; c < nchunks; ++c) {                     // ascending chunk order
+        const f32x4 p = *reinterpret_cast<const f32x4*>(ws + ((size_t)c * g.M + m) * Npad + n);
+        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(g.bias + n);
+    float v[4] = {apply_act(s.x + bb.x, g.act), apply_act(s.y + bb.y, g.act), apply_act(s.z + bb.z, g.act), apply_act(s.w + bb.w, g.act)};
+    if (g.res) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < g.res_n) v[r] += bf2f(g.res[(size_t)m * g.ldr + n + r]);
+    }
+    u32x2 o;
+    o.x = pack2bf(v[0], v[1]);
+    o.y = pack2bf(v[2], v[3]);
+    *reinterpret_cast<u32x2*>((bf16_t*)g.out + (size_t)m * g.ldo + n) = o;
+}
+
+static int launch_splitk(const GemmArgs& a, int nchunks, hipStream_t st) {
+    const size_t lds = (size_t)(SK_BM + SK_BN) * SK_LD * 2;
+    static bool attr_done[MI355_MAX_DEVICES] = {false};   // per device
+    if (first_time_on_this_device(attr_done)) {
+        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_splitk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    const int Npad = (a.N + 15) & ~15;
+    hipLaunchKernelGGL(k_gemm_splitk, dim3((unsigned)cdiv(Npad, SK_BN), (unsigned)cdiv(a.M, SK_BM), (unsigned)nchunks), dim3(256), lds, st,
+                       a, a.splitk_ws);
+    MI355_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)cdiv((long)a.M * (Npad / 4), 256)), dim3(256), 0, st, a,
+                       (const float*)a.splitk_ws, nchunks);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
 // Tile selection.  BN = 16*NT minimising padded columns (prefer fewer, larger tiles: fewer A-panel re-reads);
 // BM = 64 when a 128-row tiling would leave the 256 CUs with < 4 blocks each (late 14x14 / 7x7 layers are
 // latency-bound: more, smaller blocks overlap their load latency); BK = 64 once K >= 64.
@@ -907,6 +1034,12 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t st) {
     MI355_REQUIRE(a.out_f32 || (a.ldo % 8 == 0 && a.N % 8 == 0), "gemm: bf16 output needs N, ldo multiples of 8 (N=%d ldo=%d)",
                   a.N, a.ldo);
     MI355_REQUIRE(!a.res || a.ldr % 4 == 0, "gemm: residual stride %d must be a multiple of 4", a.ldr);
+    static const int use_splitk = getenv("MI355_GEMM_SPLITK") ? atoi(getenv("MI355_GEMM_SPLITK")) : 1;
+    if (use_splitk && a.splitk_ws && !a.out_f32 && a.ldo % 4 == 0) {
+        const int nch = gemm_splitk_chunks(a.M, a.rows_per_img > 0 ? a.rows_per_img : a.M, a.N, a.K);
+        if (nch >= 2 && gemm_splitk_bytes(a.M, a.N, a.K) <= a.splitk_ws_bytes && (!a.gate || a.gate_ld % 4 == 0))
+            return launch_splitk(a, nch, st);
+    }
     // Measured on MI355X (profiles/r01_effnet_per_op_*.txt): the 64-row / BK=64 variants lose to 128 x BN x 32
     // on every EfficientNet layer (each wave re-reads the whole W tile from LDS, so halving the rows per wave
     // makes the block LDS-bound); they stay instantiated for tiny-M problems (classifier, M = batch).

@@ -34,7 +34,7 @@ enum OpKind {
 // rotating buffers is enough; each slot is sized to the largest tensor any op writes into it.
 enum Slot {
     SLOT_NONE = -1, SLOT_X0 = 0, SLOT_X1, SLOT_E, SLOT_D, SLOT_POOLPART, SLOT_GATE, SLOT_HEAD, SLOT_POOLED,
-    SLOT_POOLED_BF16, SLOT_T0, SLOT_T1, SLOT_T2, SLOT_T3, SLOT_COUNT
+    SLOT_POOLED_BF16, SLOT_T0, SLOT_T1, SLOT_T2, SLOT_T3, SLOT_SPLITK, SLOT_COUNT
 };
 
 struct Op {

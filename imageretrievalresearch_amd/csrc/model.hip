@@ -148,6 +148,8 @@ static size_t plan_slots(mi355_model* m, int nb, int H, int W) {
             case OP_GEMM: {
                 const int h = S[op.in].h, w = S[op.in].w;
                 S[op.out].h = h; S[op.out].w = w; S[op.out].c = op.cout;
+                if (gemm_splitk_chunks((long)nb * h * w, h * w, op.cout, op.cin) >= 2)
+                    need(SLOT_SPLITK, gemm_splitk_bytes((long)nb * h * w, op.cout, op.cin));
                 need(op.out, (size_t)nb * h * w * op.cout * 2);
                 break;
             }
@@ -264,6 +266,10 @@ static int exec_op(ExecCtx& cx, const Op& op) {
             a.M = cx.nb * hw; a.N = op.cout; a.K = op.cin;
             a.act = op.act; a.a_relu6 = op.a_relu6;
             a.zeros = (const bf16_t*)cx.w(0);
+            if (m->slots[SLOT_SPLITK].bytes) {
+                a.splitk_ws = (float*)cx.slot_ptr(SLOT_SPLITK);
+                a.splitk_ws_bytes = m->slots[SLOT_SPLITK].bytes;
+            }
             return launch_gemm_bf16(a, cx.st);
         }
         case OP_DW:

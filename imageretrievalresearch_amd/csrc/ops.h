@@ -21,8 +21,15 @@ struct GemmArgs {
     int act;
     int a_relu6;
     const bf16_t* zeros;   // >= 64 bytes of device zeros (source of out-of-range DMA chunks); null disables the DMA path
+    float* splitk_ws;      // optional fp32 scratch for the split-K path (gemm_splitk_bytes); null disables it
+    size_t splitk_ws_bytes;
 };
 int launch_gemm_bf16(const GemmArgs& a, hipStream_t st);
+// Split-K for the tiny-M late projections (7x7 / 14x14 maps at small batch: a handful of output tiles, each with a serial
+// K loop of 20-70 L2 round trips).  Number of 256-deep K chunks the shape is split into, 0 = not a split-K shape.  The
+// decision looks at the layer (rows per image, K) and caps M, never at the batch position.
+int gemm_splitk_chunks(long M, int rows_per_img, int N, int K);
+size_t gemm_splitk_bytes(long M, int N, int K);
 
 // ---- fused expand(1x1, MFMA) -> depthwise -> SE squeeze for whole-image tiles (fused_mbconv.hip) ------------
 struct FusedArgs {
