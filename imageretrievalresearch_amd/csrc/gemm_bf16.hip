@@ -861,10 +861,12 @@ static int try_launch_stream(const GemmArgs& a, hipStream_t st) {
 // depends on the layer only, so an image's result does not depend on its batch position or (below the M cap) batch size.
 // =====================================================================================
 constexpr int SK_KC = 256, SK_BM = 64, SK_BN = 64, SK_LD = SK_KC + 8;
-constexpr long SK_MAX_M = 4096;
+constexpr size_t SK_MAX_BYTES = (size_t)64 << 20;       // partials of one layer: beyond this the round trip of the partials costs more than the serial K loop
 
 int gemm_splitk_chunks(long M, int rows_per_img, int N, int K) {
-    if (M > SK_MAX_M || rows_per_img > 196 || K < 512 || N < 64 || N % 8) return 0;
+    // measured (EfficientNet-B3a forward, tools/bench_small_batch.py): B=1 1.49 -> 1.04 ms, B=16 1.84 -> 1.21, B=32 1.66 -> 1.37,
+    // B=64 2.09 -> 1.99; at B=128 (M = 25 088 rows at 14x14) the partials' round trip loses (2.88 -> 3.05): M <= 16 384 rows
+    if (M > 16384 || rows_per_img > 196 || K < 512 || N < 64 || N % 8 || gemm_splitk_bytes(M, N, K) > SK_MAX_BYTES) return 0;
     return (K + SK_KC - 1) / SK_KC;
 }
 size_t gemm_splitk_bytes(long M, int N, int K) {
