@@ -170,8 +170,9 @@ def main():
         with torch.cuda.stream(s_embed):
             q64 = model(x)[:64].clone()
         s_embed.synchronize()
-        full = M.synth_fill(a.gallery * D, 5, synth.NORMAL, dev).view(a.gallery, D)
-        wv, wi = M.cosine_topk(q64, full, TOPK)
+        # the same representation the shards hold: rows normalised once (ShardedGallery / Gallery.add), scores = qn . gn
+        full = M.l2_normalize_rows(M.synth_fill(a.gallery * D, 5, synth.NORMAL, dev).view(a.gallery, D))
+        wv, wi = M.cosine_topk(q64, full, TOPK, gallery_is_normalized=True)
         del full
         torch.cuda.synchronize()
         if not (torch.equal(out[1][:64], wi) and torch.equal(out[0][:64], wv)):
