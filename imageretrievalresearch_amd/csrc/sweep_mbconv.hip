@@ -407,6 +407,8 @@ static int launch_sw_act(SweepArgs a, int B, hipStream_t st) {
 template <int KS, int S, int WI, int TH, int NW, int KST, int OCC, bool PREF>
 static int launch_sw(const SweepArgs& a, int B, hipStream_t st) {
     if (a.act_e == ACT_SILU && a.act_d == ACT_SILU) return launch_sw_act<KS, S, WI, TH, NW, KST, OCC, PREF, ACT_SILU, ACT_SILU>(a, B, st);
+    // RexNet: SiLU after the expand, nothing after the depthwise (SE + ReLU6 follow in the projection's A load)
+    if (a.act_e == ACT_SILU && a.act_d == ACT_NONE) return launch_sw_act<KS, S, WI, TH, NW, KST, OCC, PREF, ACT_SILU, ACT_NONE>(a, B, st);
     return launch_sw_act<KS, S, WI, TH, NW, KST, OCC, PREF, -1, -1>(a, B, st);
 }
 
