@@ -860,25 +860,69 @@ __global__ __launch_bounds__(SE_THREADS) void k_se(const float* __restrict__ poo
         s[c] = a * inv_hw;
     }
     __syncthreads();
+    // FC2's weights do not depend on FC1's result: the first batch (16 hidden units of this thread's channel) is requested
+    // now and travels during FC1.  (Both FC loops used `#pragma unroll N` over runtime trip counts: for rd = 6 .. 12 and C <=
+    // 288 every iteration ran in the one-at-a-time remainder loop, a dependent L2 round trip each - 8 us per launch.)
+    constexpr int NBJ = 16;
+    const int rot = (b * 192) % C;
+    int c2 = (int)tid + rot;
+    if (c2 >= C) c2 -= C;
+    const bool has_c = (int)tid < C;
+    float w2v[NBJ];
+    float b2v = 0.f;
+    if (has_c) {
+        b2v = b2[c2];
+#pragma unroll
+        for (int t = 0; t < NBJ; ++t) w2v[t] = w2t[(size_t)min(t, rd - 1) * C + c2];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     // every image's workgroup reads the same FC weights: rotate the starting row / column by the image index so the
     // co-resident workgroups do not hit the same L2 lines in lock-step (outputs are independent: order is free)
     for (int jj = wave; jj < rd; jj += SE_THREADS / 64) {
         const int j = (jj + b) % rd;
         const float* wr = w1 + (size_t)j * C;
+        const float bj = b1[j];
         float a = 0.f;
-#pragma unroll 4
-        for (int c = lane; c < C; c += 64) a += wr[c] * s[c];
+        constexpr int NBC = 8;                                  // 8 x 64 channels per batch, all loads first
+        for (int cb = 0; cb < C; cb += 64 * NBC) {
+            float wv[NBC];
+#pragma unroll
+            for (int t = 0; t < NBC; ++t) wv[t] = wr[min(cb + t * 64 + lane, C - 1)];
+#pragma unroll
+            for (int t = 0; t < NBC; ++t) {
+                const int c = cb + t * 64 + lane;
+                a += c < C ? wv[t] * s[c] : 0.f;               // ascending channel order per lane, as before
+            }
+        }
         a = wave_sum(a);
-        if (lane == 0) r[j] = apply_act(a + b1[j], act1);
+        if (lane == 0) r[j] = apply_act(a + bj, act1);
     }
     __syncthreads();
-    const int rot = (b * 192) % C;
-    for (int cc = tid; cc < C; cc += SE_THREADS) {
+    // thread tid owns channel c2 (and tid + 1024, ... for wide layers: those take the plain loop)
+    if (has_c) {
+        float a = b2v;
+#pragma unroll
+        for (int t = 0; t < NBJ; ++t) a += t < rd ? w2v[t] * r[t] : 0.f;
+        for (int j0 = NBJ; j0 < rd; j0 += NBJ) {
+            float wv[NBJ];
+#pragma unroll
+            for (int t = 0; t < NBJ; ++t) wv[t] = w2t[(size_t)min(j0 + t, rd - 1) * C + c2];
+#pragma unroll
+            for (int t = 0; t < NBJ; ++t) a += j0 + t < rd ? wv[t] * r[j0 + t] : 0.f;
+        }
+        gate[(size_t)b * C + c2] = sigmoid_f(a);
+    }
+    for (int cc = tid + SE_THREADS; cc < C; cc += SE_THREADS) {
         int c = cc + rot;
         if (c >= C) c -= C;
         float a = b2[c];
-#pragma unroll 8
-        for (int j = 0; j < rd; ++j) a += w2t[(size_t)j * C + c] * r[j];
+        for (int j0 = 0; j0 < rd; j0 += NBJ) {
+            float wv[NBJ];
+#pragma unroll
+            for (int t = 0; t < NBJ; ++t) wv[t] = w2t[(size_t)min(j0 + t, rd - 1) * C + c];
+#pragma unroll
+            for (int t = 0; t < NBJ; ++t) a += j0 + t < rd ? wv[t] * r[j0 + t] : 0.f;
+        }
         gate[(size_t)b * C + c] = sigmoid_f(a);
     }
 }
