@@ -414,8 +414,9 @@ static int launch_sw(const SweepArgs& a, int B, hipStream_t st) {
 
 // variant table {TH, NW, OCC, PREF} per class; variant 0 is the default (both K depths, any activation), the others exist only
 // for the EfficientNet-B3a instances and are kept for tuning runs (tools/tune_sweep.py)
+// (two k-steps: no cross-phase X prefetch - its 2 x MW1 x 4 extra live registers spill at the 128-VGPR budget)
 #define SW_V0(KS, S, WI, TH, NW, OCC, PREF) \
-    return k2 ? launch_sw<KS, S, WI, TH, NW, 2, OCC, PREF>(a, B, st) : launch_sw<KS, S, WI, TH, NW, 1, OCC, PREF>(a, B, st)
+    return k2 ? launch_sw<KS, S, WI, TH, NW, 2, OCC, false>(a, B, st) : launch_sw<KS, S, WI, TH, NW, 1, OCC, PREF>(a, B, st)
 #define SW_VT(KS, S, WI, TH, NW, KST, OCC, PREF) \
     return launch_sw_act<KS, S, WI, TH, NW, KST, OCC, PREF, ACT_SILU, ACT_SILU>(a, B, st)
 
