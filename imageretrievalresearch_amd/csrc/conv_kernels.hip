@@ -512,109 +512,8 @@ static int launch_dw_tiled(const bf16_t* in, const bf16_t* w, const float* bias,
 // wrap of the linear pixel index is masked per lane.  Squeeze sums: one partial per (workgroup, channel), fixed order.
 // =====================================================================================
 typedef __bf16 dw_bf16x8 __attribute__((ext_vector_type(8)));
-// NU = 8-channel units per wave: a wave does ALL units of its 32-pixel tile back to back, so the units' loads (different 16
-// bytes of the same 80-byte pixels) hit the lines the first unit pulled into L1.  (A wave per unit, the first version, sent
-// every load to L2 - 30 waves x 8 KB of lines against a 32 KB L1 - and ran at 1.3 TB/s.)
-template <int NU>
-__global__ __launch_bounds__(256, NU >= 5 ? 3 : (NU >= 4 ? 4 : 5)) void k_dw3_mfma(
-    const bf16_t* __restrict__ in, const bf16_t* __restrict__ w, const float* __restrict__ bias, bf16_t* __restrict__ out,
-    float* __restrict__ pool_partial, int B, int nblk, int H, int W, int C, int cu0, int act, unsigned magicW, int tiles_per_wg) {
-    __shared__ float red[4][NU * 8];
-    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
-    const int b = xcd + 8 * (seq / nblk), blk = seq - (seq / nblk) * nblk;
-    if (b >= B) return;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int fr = lane & 15, fq = lane >> 4;
-    const int HW = H * W;
-    const int c0 = cu0 * 8;                                               // first channel of this launch's units
-    // A fragments: lane (m = fr -> parity pm = fr >> 3, channel c = fr & 7; k group fq = t') holds k = t'*8 + c', nonzero at c' = c
-    u32x4 dwf[NU][3];
-    {
-        const int pm = fr >> 3, c = fr & 7, t = fq - pm;
-        const int q = c >> 1;
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                unsigned v = 0u;
-                if (t >= 0 && t < 3) v = w[(size_t)(ky * 3 + t) * C + c0 + u * 8 + c];
-                const unsigned word = (c & 1) ? (v << 16) : v;
-                dwf[u][ky] = (u32x4){q == 0 ? word : 0u, q == 1 ? word : 0u, q == 2 ? word : 0u, q == 3 ? word : 0u};
-            }
-    }
-    const int ch4 = (fq & 1) * 4, pp = fq >> 1;                            // this lane's 4 output channels / pixel parity
-    f32x4 bb[NU];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) bb[u] = *reinterpret_cast<const f32x4*>(bias + c0 + u * 8 + ch4);
-    const bf16_t* img = in + (size_t)b * HW * C;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(img), 0, HW * C * 2, 0x00020000);
-    bf16_t* ob = out + (size_t)b * HW * C + c0 + ch4;
-    const int rowb = W * C * 2;
-    const int ntiles = (HW + 31) >> 5;
-    const int t_end = min(ntiles, (blk + 1) * tiles_per_wg);
-    float psum[NU][4];
-#pragma unroll
-    for (int u = 0; u < NU; ++u)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) psum[u][j] = 0.f;
-    for (int tile = blk * tiles_per_wg + wave; tile < t_end; tile += 4) {
-        const int q = tile * 32 + 2 * fr;                                  // first pixel of this lane's pair (linear index, even)
-        const int y = (int)__umulhi((unsigned)q, magicW);
-        const int x = q - y * W;
-        const bool colok = !(fq == 0 && x == 0) && !(fq == 3 && x == W - 2);
-        // byte offset of input pixel q + fq - 1 (this lane's B fragment for the middle row); negative / past the image = zero
-        const int off = colok ? (q + fq - 1) * C * 2 + c0 * 2 : 0x40000000;
-        u32x4 xv[NU][3];
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            xv[u][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off - rowb + u * 16, 0, 0);
-            xv[u][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + u * 16, 0, 0);
-            xv[u][2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + rowb + u * 16, 0, 0);
-        }
-        const bool live = q + pp < HW;
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            f32x4 acc = bb[u];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const dw_bf16x8*>(&dwf[u][ky]),
-                                                              *reinterpret_cast<const dw_bf16x8*>(&xv[u][ky]), acc, 0, 0, 0);
-            MI355_ACT_DISPATCH(act, {
-                acc.x = act_c<ACT>(acc.x); acc.y = act_c<ACT>(acc.y); acc.z = act_c<ACT>(acc.z); acc.w = act_c<ACT>(acc.w);
-            })
-            if (live) {
-                psum[u][0] += acc.x; psum[u][1] += acc.y; psum[u][2] += acc.z; psum[u][3] += acc.w;
-                u32x2 o;
-                o.x = pack2bf(acc.x, acc.y);
-                o.y = pack2bf(acc.z, acc.w);
-                *reinterpret_cast<u32x2*>(ob + (size_t)(q + pp) * C + u * 8) = o;
-            }
-        }
-    }
-    if (pool_partial) {
-        // fold the 16 pixel-pair lanes and the two parities, then the four waves (fixed orders)
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) psum[u][j] += __shfl_xor(psum[u][j], o, 64);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) psum[u][j] += __shfl_xor(psum[u][j], 32, 64);
-            if (fr == 0 && fq < 2)
-                *reinterpret_cast<f32x4*>(&red[wave][u * 8 + ch4]) = (f32x4){psum[u][0], psum[u][1], psum[u][2], psum[u][3]};
-        }
-        __syncthreads();
-        if (threadIdx.x < NU * 8)
-            pool_partial[((size_t)b * nblk + blk) * C + c0 + threadIdx.x] =
-                ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-    }
-}
-
-// Same arithmetic, wave-private LDS staging: the direct version's loads and stores move 16 B per lane at an 80-byte stride
-// (every instruction touches ~22 cache lines for 1 KB).  Here a wave copies the three 34-pixel row windows of its tile with
+// Wave-private LDS staging: loading the B fragments straight from global moves 16 B per lane at an 80-byte stride (every
+// instruction touches ~22 cache lines for 1 KB; that version ran at 1.3-2.5 TB/s and was removed).  Here a wave copies the three 34-pixel row windows of its tile with
 // contiguous 16-byte loads (8 per lane instead of 15 scattered ones), reads the B fragments from LDS, and writes its 32
 // output pixels through LDS as one contiguous 32*C*2-byte run.  No barriers: a wave only touches its own LDS region, and
 // the LDS executes one wave's instructions in order.  The next tile's loads are requested before this tile's MFMAs.
@@ -755,20 +654,6 @@ static void launch_dw3_lds(const bf16_t* in, const bf16_t* w, const float* bias,
                        nb, H, W, act, magic, tpw);
 }
 
-template <int NU>
-static void launch_dw3_mfma(const bf16_t* in, const bf16_t* w, const float* bias, bf16_t* out, float* pool_partial, int B, int nb,
-                            int H, int W, int C, int cu0, int act, unsigned magic, int tpw, hipStream_t st) {
-    hipLaunchKernelGGL((k_dw3_mfma<NU>), dim3((unsigned)(8 * cdiv(B, 8) * nb)), dim3(256), 0, st, in, w, bias, out, pool_partial, B,
-                       nb, H, W, C, cu0, act, magic, tpw);
-}
-
-// MI355_DW_MFMA_LDS=0 selects the first (direct-from-global) MFMA version, kept for comparison: it is SLOWER than the VALU kernel
-// (C64 @112x112: 0.74 vs 0.29 ms), so by default the matrix-pipe path is taken only where the LDS-staged kernel applies (C <= 40)
-static int use_lds_path() {
-    static const int v = getenv("MI355_DW_MFMA_LDS") ? atoi(getenv("MI355_DW_MFMA_LDS")) : 1;
-    return v;
-}
-
 int launch_dwconv(const bf16_t* in, const bf16_t* w, const float* bias, bf16_t* out, float* pool_partial, int B, int H,
                   int W, int C, int k, int stride, int act, int* pool_nblk, hipStream_t st) {
     MI355_REQUIRE(C % 8 == 0, "dwconv: C=%d must be a multiple of 8", C);
@@ -785,38 +670,22 @@ int launch_dwconv(const bf16_t* in, const bf16_t* w, const float* bias, bf16_t* 
         return PX == 7 ? launch_dw_tiled<5, 7>(in, w, bias, out, pool_partial, B, H, W, C, TH, CGC, lds, act, pool_nblk, st)
                        : launch_dw_tiled<5, 4>(in, w, bias, out, pool_partial, B, H, W, C, TH, CGC, lds, act, pool_nblk, st);
     }
-    // narrow 3x3 stride-1 layers: MFMA kernel (0.218 -> see DESIGN.md for C40 @112x112); MI355_DW_MFMA=0 keeps the direct kernel
+    // narrow 3x3 stride-1 layers (C <= 40): matrix-pipe kernel with wave-private LDS staging (C40 @112x112: 0.218 -> 0.126 ms);
+    // MI355_DW_MFMA=0 keeps the direct kernel
     static const int use_mfma = getenv("MI355_DW_MFMA") ? atoi(getenv("MI355_DW_MFMA")) : 1;
-    if (use_mfma && k == 3 && stride == 1 && C <= (use_lds_path() ? 40 : 64) && W % 2 == 0 && W >= 4 && (long)H * W * C * 2 < (1L << 30)) {
+    if (use_mfma && k == 3 && stride == 1 && C <= 40 && W % 2 == 0 && W >= 4 && (long)H * W * C * 2 < (1L << 30)) {
         const int ntiles = cdiv((long)H * W, 32);
         int nb = std::min(std::min(dw_pool_blocks(Ho, Wo, C), 14), ntiles);      // <= the squeeze-partial slot the planner sized
         const int tpw = cdiv(ntiles, nb);
         nb = cdiv(ntiles, tpw);
         if (pool_nblk) *pool_nblk = nb;
         const unsigned magic = (unsigned)((0x100000000ULL + (unsigned)W - 1) / (unsigned)W);
-        if (use_lds_path() && C <= 40) {
-            switch (C / 8) {
-                case 1: launch_dw3_lds<1>(in, w, bias, out, pool_partial, B, nb, H, W, act, magic, tpw, st); break;
-                case 2: launch_dw3_lds<2>(in, w, bias, out, pool_partial, B, nb, H, W, act, magic, tpw, st); break;
-                case 3: launch_dw3_lds<3>(in, w, bias, out, pool_partial, B, nb, H, W, act, magic, tpw, st); break;
-                case 4: launch_dw3_lds<4>(in, w, bias, out, pool_partial, B, nb, H, W, act, magic, tpw, st); break;
-                default: launch_dw3_lds<5>(in, w, bias, out, pool_partial, B, nb, H, W, act, magic, tpw, st); break;
-            }
-            MI355_LAUNCH_CHECK();
-            return OK;
-        }
-        // up to 5 units (40 channels) per wave; wider layers go out as several launches over unit ranges
-        for (int cu0 = 0; cu0 < C / 8;) {
-            const int left = C / 8 - cu0;
-            const int nu = left <= 5 ? left : (left == 6 ? 3 : 4);
-            switch (nu) {
-                case 1: launch_dw3_mfma<1>(in, w, bias, out, pool_partial, B, nb, H, W, C, cu0, act, magic, tpw, st); break;
-                case 2: launch_dw3_mfma<2>(in, w, bias, out, pool_partial, B, nb, H, W, C, cu0, act, magic, tpw, st); break;
-                case 3: launch_dw3_mfma<3>(in, w, bias, out, pool_partial, B, nb, H, W, C, cu0, act, magic, tpw, st); break;
-                case 4: launch_dw3_mfma<4>(in, w, bias, out, pool_partial, B, nb, H, W, C, cu0, act, magic, tpw, st); break;
-                default: launch_dw3_mfma<5>(in, w, bias, out, pool_partial, B, nb, H, W, C, cu0, act, magic, tpw, st); break;
-            }
-            cu0 += nu;
+        switch (C / 8) {
+            case 1: launch_dw3_lds<1>(in, w, bias, out, pool_partial, B, nb, H, W, act, magic, tpw, st); break;
+            case 2: launch_dw3_lds<2>(in, w, bias, out, pool_partial, B, nb, H, W, act, magic, tpw, st); break;
+            case 3: launch_dw3_lds<3>(in, w, bias, out, pool_partial, B, nb, H, W, act, magic, tpw, st); break;
+            case 4: launch_dw3_lds<4>(in, w, bias, out, pool_partial, B, nb, H, W, act, magic, tpw, st); break;
+            default: launch_dw3_lds<5>(in, w, bias, out, pool_partial, B, nb, H, W, act, magic, tpw, st); break;
         }
         MI355_LAUNCH_CHECK();
         return OK;
