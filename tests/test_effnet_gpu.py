@@ -65,6 +65,23 @@ def test_every_block_matches_bf16_sim_oracle(setup):
     print("worst tap", worst)
 
 
+def test_other_input_size_takes_the_general_kernels(setup):
+    """200 x 200 images: the stem output is 100 x 100 (10 000 pixels = 312.5 tiles of 32: the MFMA depthwise kernel's partial
+    last tile), and none of the row-sweep kernel's shape classes (112 / 56 / 28) applies, so the band / unfused kernels run -
+    same tap tolerances against the oracle."""
+    sd, model = setup
+    x = torch.from_numpy(images(9, 2, H=200, W=200))
+    taps = {}
+    want = effnet.forward_features(sd, x, sim_bf16=True, taps=taps)
+    model.enable_taps(True)
+    got = model.forward_features(x.to(DEV))
+    for name in ("stem", "blocks.0.0", "blocks.0.1", "blocks.1.0", "blocks.2.0", "blocks.3.1", "blocks.6.1"):
+        e = rel(model.read_tap(name).cpu(), taps[name])
+        assert e < TOL_LAYER_SIM, f"tap {name} at 200x200: rel L2 {e:.3e}"
+    model.enable_taps(False)
+    assert got.shape == want.shape and rel(got.cpu(), want) < TOL_LAYER_SIM
+
+
 def test_embedding_vs_fp32_reference_semantics(setup):
     sd, model = setup
     x = torch.from_numpy(images(3, 4))
