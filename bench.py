@@ -206,18 +206,28 @@ def main():
         ops = model.profile_ops(a.batch)
         model.set_option("profile", 0)
         tr = model.traffic(a.batch)
-        groups = []                                    # (label, kind, avg ms per launch, algorithmic bytes per launch)
+        groups = []                                    # (label, kind, avg ms per launch, algorithmic bytes per launch, ops, key)
         for lab, kind, ms, by in ops:
             if ms > 0:
-                groups.append([lab, kind, ms, by, 1])
+                groups.append([lab, kind, ms, by, 1, lab])
             elif groups:
                 groups[-1][3] += by                    # an op executed inside the previous launch
                 groups[-1][4] += 1
-        top = max(groups, key=lambda g: g[2])
-        kernel_of = {1: {"gemm": "k_gemm_bf16 / k_gemm_big / k_gemm_stream (1x1 conv)", "dw": "k_dwconv / k_dw3_lds", "stem": "k_stem",
+                groups[-1][5] += " + " + lab
+        # the dominant KERNEL = the launches of identical layer shape (same ops, same shapes: one kernel instantiation) with
+        # the largest total time per forward, as `rocprofv3 --stats` ranks kernel symbols; its roofline uses the mean launch
+        by_key = {}
+        for g_ in groups:
+            e = by_key.setdefault(g_[5], {"first": g_, "ms": 0.0, "n": 0})
+            e["ms"] += g_[2]
+            e["n"] += 1
+        dom = max(by_key.values(), key=lambda e: e["ms"])
+        top = list(dom["first"])
+        top[2] = dom["ms"] / dom["n"]
+        kernel_of = {1: {"gemm": "k_gemm_bf16 / k_proj_lds / k_gemm_big / k_gemm_stream (1x1 conv)", "dw": "k_dwconv / k_dw3_lds", "stem": "k_stem",
                          "se": "k_se", "attn": "k_win_attn", "ln": "k_layernorm", "other": "other"},
                      2: "k_fused_late (1x1 expand + depthwise + SE squeeze on a whole-image tile, expanded tensor in LDS)",
-                     4: "k_mbconv_block (whole MBConv block: expand, MFMA depthwise, SE, gated projection, residual)"}
+                     4: "k_mbconv_block (whole MBConv block: expand, MFMA depthwise, SE, gated projection, residual; the expanded tensor stays in LDS, the depthwise output makes one L2 round trip)"}
         if top[4] == 2 and any(t in top[0] for t in ("@112x112", "@56x56", "@28x28")):
             kname = ("k_sweep_mbconv (row sweep: 1x1 expand on MFMA + depthwise on MFMA from an LDS row window + SE squeeze; the "
                      "expanded tensor never reaches HBM, so the layer-granular bytes below exceed what the launch moves)")
@@ -238,7 +248,11 @@ def main():
                     traffic_source = "profiles/r02_pmc_traffic_effnet_b256.json (rocprofv3 --pmc, separate passes, same kernel sources)"
         roofline = {"bound": "hbm", "kernel": f"{kname} @ {top[0]}", "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                    "avg_launch_ms": top[2], "algorithmic_bytes_per_launch": top[3],
+                    "avg_launch_ms": top[2], "launches_per_forward": dom["n"], "ms_per_forward": dom["ms"],
+                    "ops_in_launch": top[5], "algorithmic_bytes_per_launch": top[3],
+                    "bytes_model": "SURVEY 8d layer-granular bytes of every op the launch executes (fused intermediates included)",
+                    "note": "fused kernels are VALU / latency-bound, not HBM-bound (PMC per launch: profiles/r02_pmc_traffic_effnet_b256.json; "
+                            "whole-forward fraction: embed_roofline)",
                     "family_ms_per_forward": {k: v["ms"] / nprof for k, v in prof.items() if v["launches"]},
                     "family_GBps": {k: tr["bytes_by_kind"][k] / (v["ms"] / nprof * 1e-3) / 1e9
                                     for k, v in prof.items() if v["launches"] and tr["bytes_by_kind"].get(k)}}
