@@ -1,8 +1,10 @@
-"""The committed bench line (profiles/r01_bench_n1.json, produced by `python bench.py` on an MI355X) carries every field
+"""The committed bench lines (profiles/rNN_bench_n1.json, produced by `python bench.py` on an MI355X) carry every field
 of the driver's contract, and bench.py still emits those keys (static check of the source: no GPU here)."""
 import json
 import os
 import re
+
+import pytest
 
 from helpers import ROOT
 
@@ -12,8 +14,9 @@ ROOFLINE = ["bound", "achieved", "peak", "unit", "frac", "traffic"]
 CPU = ["value", "unit", "cores", "kind", "sample"]
 
 
-def test_committed_bench_line_has_the_contract_fields():
-    line = open(os.path.join(ROOT, "profiles", "r01_bench_n1.json")).read().strip().splitlines()[-1]
+@pytest.mark.parametrize("name", ["r01_bench_n1.json", "r02_bench_n1.json"])
+def test_committed_bench_line_has_the_contract_fields(name):
+    line = open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1]
     d = json.loads(line)
     for k in REQUIRED:
         assert k in d, k
@@ -26,6 +29,8 @@ def test_committed_bench_line_has_the_contract_fields():
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-9
     assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["cpu_baseline"]["cores"] >= 1
     assert "workload" in d["config"] and "model" not in d["config"]
+    if name.startswith("r02"):
+        assert d["roofline"]["traffic"] and d["roofline"]["launches_per_forward"] >= 1   # PMC traffic of the same sources
     # value = images of all ranks / time of the timed steps
     assert abs(d["value"] - d["config"]["batch_per_gpu"] * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
 
