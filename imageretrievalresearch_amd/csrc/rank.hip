@@ -1,14 +1,20 @@
-// Rank half of the hot path: row normalisation, exact-f32 MFMA cosine GEMM, top-k selection,
-// shard merge, pair cosine, ContrastiveLoss, hit counting.  gfx950 only.
+// Rank half of the hot path: row normalisation, cosine GEMM with fused top-k selection, shard merge, pair cosine,
+// ContrastiveLoss, hit counting.  gfx950 only.
 //
 // Reference semantics: torch.nn.CosineSimilarity(dim=1, eps=1e-6) + torch.topk as called at
-// train/train.py:250-251 (see include/mi355_retrieval.h).  Everything here is fp32: the GEMM runs on
-// v_mfma_f32_32x32x2_f32, which is bit-for-bit an fmaf chain (no reduced-precision path), so an
-// index can only differ from the CPU oracle where two scores are closer than fp32 summation noise.
+// train/train.py:250-251 (see include/mi355_retrieval.h).  Inputs, norms, accumulation and scores are fp32.  The
+// GEMM has two loops with the same tiling and epilogue:
+//   * default: fp32 operands split into three bf16 planes, six of the nine bf16 products per element on
+//     v_mfma_f32_32x32x16_bf16 with fp32 accumulation (k_cos_gemm_split; error per product <= 2^-23, the size of the
+//     one rounding an fmaf spends - measured as close to the float64 cosine as the exact loop, ~1e-7);
+//   * MI355_RANK_EXACT_F32=1, gallery rows not 16-byte aligned, or Q <= 4 (GEMV): v_mfma_f32_32x32x2_f32 / fmaf, bit-for-bit
+//     an fp32 fmaf chain (2.7x the matrix-pipe time).
+// Either way an index can only differ from the CPU oracle where two scores are closer than fp32 summation noise.
 #include "common.h"
 #include "../../include/mi355_retrieval.h"
 
 #include <limits.h>
+#include <stdlib.h>
 #include <math.h>
 
 namespace mi355 {
@@ -90,6 +96,64 @@ __device__ __forceinline__ float key_score(unsigned key) {
 }
 
 // =====================================================================================
+// fp32 operands on the bf16 matrix pipe: three-way split, six products
+// =====================================================================================
+// x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (round-to-nearest-even; both subtractions are exact
+// in fp32, and |x - h - m - l| <= 2^-25 |x|: the three 8-bit significands cover fp32's 24).  A product x*y is then the sum
+// of nine bf16 x bf16 products, each EXACT in the fp32 accumulator; the kernel keeps the six largest
+//     h*h' + (h*m' + m*h') + (h*l' + l*h' + m*m')
+// and drops m*l', l*m', l*l' (<= 2^-24 |x*y| each, either sign).  Per product that is the size of ONE fp32 rounding -
+// what the exact-fp32 MFMA (an fmaf chain) spends on every product anyway - so scores agree with the fp32 chain to
+// ~1e-7 (measured against the fp64 oracle in tests/test_rank_gpu.py); the accumulation itself stays fp32.  Six
+// v_mfma_f32_32x32x16_bf16 do the work of eight v_mfma_f32_32x32x2_f32 in 3/8 of the matrix-pipe time (192 vs 512 cycles).
+// NaN / Inf inputs give NaN scores (Inf - Inf in the split), which the selection orders as torch.topk does.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = pack2bf(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = pack2bf(r0, r1);
+    l = pack2bf(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
+}
+__device__ __forceinline__ void split3(const f32x4 a, const f32x4 b, u32x4& h, u32x4& m, u32x4& l) {
+    unsigned hh[4], mm[4], ll[4];
+    split3_pair(a.x, a.y, hh[0], mm[0], ll[0]);
+    split3_pair(a.z, a.w, hh[1], mm[1], ll[1]);
+    split3_pair(b.x, b.y, hh[2], mm[2], ll[2]);
+    split3_pair(b.z, b.w, hh[3], mm[3], ll[3]);
+    h = (u32x4){hh[0], hh[1], hh[2], hh[3]};
+    m = (u32x4){mm[0], mm[1], mm[2], mm[3]};
+    l = (u32x4){ll[0], ll[1], ll[2], ll[3]};
+}
+
+// Normalised queries -> split planes in MFMA-fragment order: Qs[row block of 32][k step of 16][plane h,m,l][lane][8 bf16],
+// lane = row + 32 * (k half): every (row block, k step, plane) is 1 KB that one global_load_lds moves into LDS exactly as
+// the A operand of v_mfma_f32_32x32x16_bf16 wants it (lane-linear ds_read_b128, no padding, no swizzle).  Rows >= Q and
+// k >= D are zero.  A 256-byte zero page follows the planes (source of the GEMM's out-of-range gallery loads).
+__global__ __launch_bounds__(256) void k_split_queries(const float* __restrict__ Qn, bf16_t* __restrict__ Qs, int Q, int D,
+                                                       int n_steps, int n_frag) {
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);   // fragment = (row block, k step)
+    if (blockIdx.x == 0 && threadIdx.x < 64) reinterpret_cast<unsigned*>(Qs + (size_t)n_frag * 3 * 512)[threadIdx.x] = 0u;   // zero page
+    if (f >= n_frag) return;
+    const int lane = threadIdx.x & 63;
+    const int rb = f / n_steps, s = f % n_steps;
+    const int row = rb * 32 + (lane & 31), k0 = s * 16 + (lane >> 5) * 8;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (row < Q && k0 + e < D) ? Qn[(i64)row * D + k0 + e] : 0.f;
+    u32x4 h, m, l;
+    split3((f32x4){x[0], x[1], x[2], x[3]}, (f32x4){x[4], x[5], x[6], x[7]}, h, m, l);
+    u32x4* o = reinterpret_cast<u32x4*>(Qs + (size_t)f * 3 * 512) + lane;
+    o[0] = h; o[64] = m; o[128] = l;
+}
+
+__device__ __forceinline__ void glds16(const bf16_t* gsrc, bf16_t* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// =====================================================================================
 // cosine GEMM:  S[q][g] = sum_d Qn[q][d] * Gal[g][d] * (ginv ? ginv[g] : 1)
 // =====================================================================================
 // Block = 4 waves as 2(M) x 2(N); wave tile = (MT*32) queries x 64 gallery rows; block tile =
@@ -98,6 +162,115 @@ __device__ __forceinline__ float key_score(unsigned key) {
 // Per lane a float4 at k = 8t + 4*(lane>>5) feeds four 32x32x2 k-steps; A and B use the same k
 // permutation, which only reorders the (exact) fma chain.
 constexpr int RK_BN = 128;
+
+// Epilogue shared by the exact-fp32 and the split-bf16 loops (same accumulator layout: the C/D map of the 32x32 MFMAs does
+// not depend on the input type): FK = 0 writes the score slab, FK > 0 selects per-tile candidates.  Called after a
+// __syncthreads() that retired every read of the staging buffers (smem is reused).
+template <int MT, int FK>
+__device__ __forceinline__ void cos_gemm_epilogue(f32x16 (&acc)[MT][2], float* smem, const float* __restrict__ ginv,
+                                                  float* __restrict__ S, int Q, i64 G, int k, float* __restrict__ cand_val,
+                                                  int* __restrict__ cand_idx, int x0, int ntx, i64 n0, int m0) {
+    constexpr int BM = 64 * MT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31;
+    if constexpr (FK > 0) {
+        // (the loop's last __syncthreads() retired every read of the staging buffers)
+        // 64 query rows at a time, so that the transposed tile (64 x 132 floats = 33.8 KB) fits inside the staging
+        // buffers: a bigger LDS request would cost the third resident workgroup per CU and with it a round of tiles
+        constexpr int CLD = RK_BN + 4;                 // 132 floats: a thread per row reads float4s conflict-free
+        float* Ct = smem;                              // [64][CLD]
+        const i64 ncol = (G - n0 < RK_BN) ? G - n0 : RK_BN;     // valid columns of this tile
+#pragma unroll 1
+        for (int h = 0; h < BM / 64; ++h) {
+            if ((wm * MT * 32) / 64 == h) {            // this wave's rows belong to pass h
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const i64 col = n0 + wn * 64 + j * 32 + lr;
+                    const float gs = (ginv && col < G) ? ginv[col] : 1.0f;
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = (wm * MT * 32) % 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                            Ct[row * CLD + wn * 64 + j * 32 + lr] = acc[i][j][r] * gs;
+                        }
+                }
+            }
+            __syncthreads();
+            // Selection: FOUR threads per query row, each scans 32 columns in ascending order into a sorted FK-list held as
+            // order-preserving integer keys (NaN = largest, -0 = +0); the insertion is branch-free (a divergent insertion
+            // sort cost 10 % of the tile: some lane of the wave inserts at almost every column) and skipped by a wave vote
+            // when no lane beats its FK-th entry.  The row's four lists are merged through shuffles in column order, so
+            // ties keep resolving to the lower index.
+            {
+                const int lrow = tid >> 2, part = tid & 3;
+                unsigned kv[FK];
+                int ki[FK];
+#pragma unroll
+                for (int i = 0; i < FK; ++i) { kv[i] = 0u; ki[i] = IDX32_PAD; }      // key 0 = below every real score (-inf is 0x007fffff)
+                auto insert = [&](unsigned key, int id) {
+                    bool g[FK];
+#pragma unroll
+                    for (int i = 0; i < FK; ++i) g[i] = key > kv[i];          // strict: an equal score keeps the earlier (lower) index
+#pragma unroll
+                    for (int i = FK - 1; i > 0; --i) {
+                        kv[i] = g[i] ? (g[i - 1] ? kv[i - 1] : key) : kv[i];
+                        ki[i] = g[i] ? (g[i - 1] ? ki[i - 1] : id) : ki[i];
+                    }
+                    kv[0] = g[0] ? key : kv[0];
+                    ki[0] = g[0] ? id : ki[0];
+                };
+                const float* rowp = Ct + lrow * CLD + part * 32;
+#pragma unroll 2
+                for (int c4i = 0; c4i < 8; ++c4i) {
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(rowp + c4i * 4);
+                    const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = part * 32 + c4i * 4 + e;
+                        unsigned key = score_key(vv[e]);
+                        if (c >= ncol) key = 0u;
+                        if (__any(key > kv[FK - 1])) insert(key, (int)n0 + c);      // n0 + c < 2^31 (checked on the host)
+                    }
+                }
+                // merge parts 1..3 into part 0 (lanes 4r .. 4r+3 of one wave)
+#pragma unroll
+                for (int src = 1; src < 4; ++src) {
+#pragma unroll
+                    for (int i = 0; i < FK; ++i) {
+                        const unsigned ok = (unsigned)__shfl(kv[i], (lane & ~3) + src, 64);
+                        const int oi = __shfl(ki[i], (lane & ~3) + src, 64);
+                        if (part == 0) insert(ok, oi);
+                    }
+                }
+                const int qrow = m0 + h * 64 + lrow;
+                if (part == 0 && qrow < Q) {
+                    const size_t o = ((size_t)qrow * ntx + blockIdx.x + x0) * k;
+#pragma unroll
+                    for (int i = 0; i < FK; ++i)
+                        if (i < k) { cand_val[o + i] = ki[i] == IDX32_PAD ? NEG_INF : key_score(kv[i]); cand_idx[o + i] = ki[i]; }
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // epilogue: C[row = query][col = gallery]; lane: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const i64 col = n0 + wn * 64 + j * 32 + lr;
+        if (col >= G) continue;
+        const float gs = ginv ? ginv[col] : 1.0f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * MT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < Q) S[(i64)row * G + col] = acc[i][j][r] * gs;
+            }
+        }
+    }
+}
 
 // FK = 0: write the score slab S.  FK = 1/2/4/8 (fused selection, k <= FK): the score tile never leaves the CU - it is
 // transposed through LDS (the staging buffers are free after the K loop), each of the tile's query rows is scanned by one
@@ -220,103 +393,157 @@ __global__ __launch_bounds__(256) void k_cos_gemm(const float* __restrict__ Qn, 
         __syncthreads();
     }
 
-    if constexpr (FK > 0) {
-        // (the loop's last __syncthreads() retired every read of the staging buffers)
-        // 64 query rows at a time, so that the transposed tile (64 x 132 floats = 33.8 KB) fits inside the staging
-        // buffers: a bigger LDS request would cost the third resident workgroup per CU and with it a round of tiles
-        constexpr int CLD = RK_BN + 4;                 // 132 floats: a thread per row reads float4s conflict-free
-        float* Ct = smem;                              // [64][CLD]
-        const i64 ncol = (G - n0 < RK_BN) ? G - n0 : RK_BN;     // valid columns of this tile
-#pragma unroll 1
-        for (int h = 0; h < BM / 64; ++h) {
-            if ((wm * MT * 32) / 64 == h) {            // this wave's rows belong to pass h
+    cos_gemm_epilogue<MT, FK>(acc, smem, ginv, S, Q, G, k, cand_val, cand_idx, x0, ntx, n0, m0);
+}
+
+// =====================================================================================
+// The same GEMM on the bf16 matrix pipe (three-way split, six products; see split3 above).  Same block / wave tiling and
+// the same epilogue as k_cos_gemm; BK = 16 (one 32x32x16 k-step per K-tile).  Needs 16-byte aligned gallery rows
+// (D % 4 == 0); other shapes stay on the fp32 loop.
+//   A (queries): pre-split planes in fragment order (k_split_queries), 1 KB per (row block, plane) by LDS-DMA, one
+//     k-step ahead (they come from L2);
+//   B (gallery): fp32 rows by LDS-DMA as well, TWO k-steps ahead (they come from HBM): a piece is 16 rows x 64 B, the
+//     16-byte chunk c of row r lands at position c ^ ((r >> 2) & 3) (the swizzle is applied to the per-lane SOURCE address,
+//     the DMA writes lane-linear), so that the ds_read_b128 of 8 rows hit 8 different bank groups without padding.  Each
+//     wave reads its two 32-row fragments (8 consecutive k per lane) and splits them in registers - 44 VALU instructions
+//     per fragment next to the 12 MFMAs (384 matrix-pipe cycles) that consume it.
+// No load in the loop has a register destination, so the only waits are the ones written here: ONE vmcnt(2) per k-step
+// (the counter retires in order: everything but this iteration's two B pieces - issued last - has landed) and one
+// LDS-only barrier.  (With register-staged B loads hipcc drained vmcnt(0) before every store to LDS.)
+// LDS: 2 x MT x 6 KB (A) + 3 x 8 KB (B) = 48 KB at MT = 2 -> three workgroups per CU.
+// =====================================================================================
+template <int MT, int FK>
+__global__ __launch_bounds__(256, 3) void k_cos_gemm_split(const bf16_t* __restrict__ Qs, const float* __restrict__ Gal,
+                                                           const float* __restrict__ ginv, float* __restrict__ S, int Q,
+                                                           i64 G, int D, int k, float* __restrict__ cand_val,
+                                                           int* __restrict__ cand_idx, int x0, int ntx, int n_steps,
+                                                           const float* __restrict__ zeros) {
+    constexpr int BM = 64 * MT;
+    constexpr int BK = 16;
+    constexpr int A_STAGE = (BM / 32) * 3 * 512;      // bf16 elements per stage
+    constexpr int A_PIECES = (BM / 32) * 3;           // 1 KB pieces per stage
+    constexpr int B_STAGE = RK_BN * BK;               // floats per stage (8 KB)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    bf16_t* As = reinterpret_cast<bf16_t*>(smem);                       // [2][BM/32][3][512]
+    float* Bs = smem + (2 * A_STAGE * 2) / 4;                           // [3][128][16], chunks swizzled
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const i64 n0 = (i64)(blockIdx.x + x0) * RK_BN;
+    const int m0 = blockIdx.y * BM;
+    // the wave index as a scalar: piece selection becomes scalar branches (a per-lane branch around a load makes hipcc
+    // drain vmcnt)
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+
+    // B: wave w moves pieces 2w and 2w + 1 (rows 32w .. 32w + 31); lane -> row 16 * piece + lane / 4, position lane % 4
+    const float* b_row[2];
+    int b_k[2];
+    bool b_ok[2];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const i64 col = n0 + wn * 64 + j * 32 + lr;
-                    const float gs = (ginv && col < G) ? ginv[col] : 1.0f;
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int row = (wm * MT * 32) % 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                            Ct[row * CLD + wn * 64 + j * 32 + lr] = acc[i][j][r] * gs;
-                        }
-                }
-            }
-            __syncthreads();
-            // Selection: FOUR threads per query row, each scans 32 columns in ascending order into a sorted FK-list held as
-            // order-preserving integer keys (NaN = largest, -0 = +0); the insertion is branch-free (a divergent insertion
-            // sort cost 10 % of the tile: some lane of the wave inserts at almost every column) and skipped by a wave vote
-            // when no lane beats its FK-th entry.  The row's four lists are merged through shuffles in column order, so
-            // ties keep resolving to the lower index.
-            {
-                const int lrow = tid >> 2, part = tid & 3;
-                unsigned kv[FK];
-                int ki[FK];
-#pragma unroll
-                for (int i = 0; i < FK; ++i) { kv[i] = 0u; ki[i] = IDX32_PAD; }      // key 0 = below every real score (-inf is 0x007fffff)
-                auto insert = [&](unsigned key, int id) {
-                    bool g[FK];
-#pragma unroll
-                    for (int i = 0; i < FK; ++i) g[i] = key > kv[i];          // strict: an equal score keeps the earlier (lower) index
-#pragma unroll
-                    for (int i = FK - 1; i > 0; --i) {
-                        kv[i] = g[i] ? (g[i - 1] ? kv[i - 1] : key) : kv[i];
-                        ki[i] = g[i] ? (g[i - 1] ? ki[i - 1] : id) : ki[i];
-                    }
-                    kv[0] = g[0] ? key : kv[0];
-                    ki[0] = g[0] ? id : ki[0];
-                };
-                const float* rowp = Ct + lrow * CLD + part * 32;
-#pragma unroll 2
-                for (int c4i = 0; c4i < 8; ++c4i) {
-                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(rowp + c4i * 4);
-                    const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int c = part * 32 + c4i * 4 + e;
-                        unsigned key = score_key(vv[e]);
-                        if (c >= ncol) key = 0u;
-                        if (__any(key > kv[FK - 1])) insert(key, (int)n0 + c);      // n0 + c < 2^31 (checked on the host)
-                    }
-                }
-                // merge parts 1..3 into part 0 (lanes 4r .. 4r+3 of one wave)
-#pragma unroll
-                for (int src = 1; src < 4; ++src) {
-#pragma unroll
-                    for (int i = 0; i < FK; ++i) {
-                        const unsigned ok = (unsigned)__shfl(kv[i], (lane & ~3) + src, 64);
-                        const int oi = __shfl(ki[i], (lane & ~3) + src, 64);
-                        if (part == 0) insert(ok, oi);
-                    }
-                }
-                const int qrow = m0 + h * 64 + lrow;
-                if (part == 0 && qrow < Q) {
-                    const size_t o = ((size_t)qrow * ntx + blockIdx.x + x0) * k;
-#pragma unroll
-                    for (int i = 0; i < FK; ++i)
-                        if (i < k) { cand_val[o + i] = ki[i] == IDX32_PAD ? NEG_INF : key_score(kv[i]); cand_idx[o + i] = ki[i]; }
-                }
-            }
-            __syncthreads();
-        }
-        return;
+    for (int i = 0; i < 2; ++i) {
+        const int r = (swave * 2 + i) * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((r >> 2) & 3);
+        b_ok[i] = n0 + r < G;
+        b_row[i] = Gal + (b_ok[i] ? (n0 + r) * D : 0);
+        b_k[i] = c * 4;
     }
-    // epilogue: C[row = query][col = gallery]; lane: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    auto dma_b = [&](int stage, int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = b_ok[i] && k0 + b_k[i] < D;                // D % 4 == 0: a chunk is inside or outside
+            glds16(reinterpret_cast<const bf16_t*>(ok ? b_row[i] + k0 + b_k[i] : zeros),
+                   reinterpret_cast<bf16_t*>(Bs + stage * B_STAGE + (swave * 2 + i) * 256));
+        }
+    };
+    // A: piece (row block rbl, plane p) of k-step t sits at Qs + (((m0/32 + rbl) * n_steps + t) * 3 + p) * 512.
+    // 12 (MT = 2) or 6 (MT = 1) pieces per stage: wave w moves pieces w, w + 4, w + 8 / pieces w and (w < 2) w + 4.
+    const bf16_t* a_src = Qs + (size_t)(m0 / 32) * n_steps * 3 * 512 + lane * 8;
+    const bf16_t* a_piece[(A_PIECES + 3) / 4];
+#pragma unroll
+    for (int i = 0; i < (A_PIECES + 3) / 4; ++i) {
+        const int piece = (swave + 4 * i) % A_PIECES;
+        a_piece[i] = a_src + ((size_t)((piece / 3) * n_steps) * 3 + piece % 3) * 512;
+    }
+    auto dma_a = [&](int buf, int t) {
+#pragma unroll
+        for (int i = 0; i < (A_PIECES + 3) / 4; ++i) {
+            const int piece = swave + 4 * i;
+            if (A_PIECES % 4 == 0 || i < A_PIECES / 4 || swave < A_PIECES % 4)
+                glds16(a_piece[i] + (size_t)t * 3 * 512, As + buf * A_STAGE + piece * 512);
+        }
+    };
+
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int lr = lane & 31;
+    // B fragment reads: row r = wn * 64 + j * 32 + lr, chunks 2 * (lane >> 5) and + 1 at their swizzled positions
+    int b_off[2][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const i64 col = n0 + wn * 64 + j * 32 + lr;
-        if (col >= G) continue;
-        const float gs = ginv ? ginv[col] : 1.0f;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * MT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < Q) S[(i64)row * G + col] = acc[i][j][r] * gs;
-            }
-        }
+        const int r = wn * 64 + j * 32 + lr, sw = (r >> 2) & 3, c0 = (lane >> 5) * 2;
+        b_off[j][0] = r * BK + ((c0 ^ sw) << 2);
+        b_off[j][1] = r * BK + (((c0 + 1) ^ sw) << 2);
     }
+    auto compute = [&](int abuf, int bstage) {
+        const bf16_t* a = As + abuf * A_STAGE + (wm * MT * 3) * 512 + lane * 8;
+        const float* b = Bs + bstage * B_STAGE;
+        bf16x8 af[MT][3];
+        u32x4 bh[2], bm[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(a + (i * 3 + p) * 512);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(b + b_off[j][0]);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(b + b_off[j][1]);
+            split3(v0, v1, bh[j], bm[j], bl[j]);
+        }
+        // smallest terms first; the order is the same for every (query, gallery row) pair wherever its tile lies
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bf16x8 gh = *reinterpret_cast<const bf16x8*>(&bh[j]);
+                const bf16x8 gm = *reinterpret_cast<const bf16x8*>(&bm[j]);
+                const bf16x8 gl = *reinterpret_cast<const bf16x8*>(&bl[j]);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], gh, acc[i][j], 0, 0, 0);   // l * h'
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], gl, acc[i][j], 0, 0, 0);   // h * l'
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], gm, acc[i][j], 0, 0, 0);   // m * m'
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], gh, acc[i][j], 0, 0, 0);   // m * h'
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], gm, acc[i][j], 0, 0, 0);   // h * m'
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], gh, acc[i][j], 0, 0, 0);   // h * h'
+            }
+    };
+
+    dma_a(0, 0);
+    dma_b(0, 0);
+    dma_b(1, BK);                      // (zeros past D)
+    __syncthreads();                   // drains vmcnt: everything has landed
+
+    int bs_cur = 0, bs_far = 2;        // B stage of k-step t / of k-step t + 2
+    for (int t = 0; t < n_steps; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < n_steps) dma_a(buf ^ 1, t + 1);          // everybody left these buffers at the previous barrier
+        __builtin_amdgcn_sched_barrier(0);                   // (the count below needs the A pieces issued BEFORE the B pieces)
+        dma_b(bs_far, (t + 2) * BK);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(buf, bs_cur);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // A(t+1) and B(t+1) have landed; B(t+2) stays in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        bs_cur = bs_cur == 2 ? 0 : bs_cur + 1;
+        bs_far = bs_far == 2 ? 0 : bs_far + 1;
+    }
+    __syncthreads();                   // the last look-ahead pieces (zeros) have landed before the epilogue reuses the LDS
+    cos_gemm_epilogue<MT, FK>(acc, smem, ginv, S, Q, G, k, cand_val, cand_idx, x0, ntx, n0, m0);
 }
 
 // =====================================================================================
@@ -692,8 +919,9 @@ static bool fused_select(i64 Q, i64 G, int k) { return k >= 1 && k <= SMALL_K &&
 
 static i64 query_block(i64 Q, i64 G, int k) {
     if (fused_select(Q, G, k)) {
-        // no score slab: candidates are cdiv(G,128) * k * 8 B per query; keep them <= 256 MiB per block of queries
-        i64 qb = ((i64)1 << 28) / (cdiv(G, RK_BN) * (i64)k * 8);
+        // no score slab: candidates are cdiv(G,128) * k * 8 B per query; keep them <= 32 MiB per block of queries (a second
+        // block costs one more pass over the gallery, which a GEMM of >= 1000 queries hides)
+        i64 qb = ((i64)1 << 25) / (cdiv(G, RK_BN) * (i64)k * 8);
         qb = qb / 128 * 128;
         if (qb < 128) qb = 128;
         return qb < Q ? qb : Q;
@@ -706,8 +934,10 @@ static i64 query_block(i64 Q, i64 G, int k) {
 }
 
 struct RankWs {
-    float* qn; float* ginv; float* S; float* cand_val; int* cand_idx; void* topk; size_t topk_bytes; size_t total;
+    float* qn; bf16_t* qs; float* ginv; float* S; float* cand_val; int* cand_idx; void* topk; size_t topk_bytes; size_t total;
 };
+// split query planes (k_split_queries): whole 128-row tiles, 16-deep k steps, three planes
+static size_t split_queries_bytes(i64 Q, int D) { return (size_t)cdiv(Q, 128) * 4 * cdiv(D, 16) * 3 * 1024 + 256; }
 static RankWs carve(void* ws, i64 Q, i64 G, int D, int k, bool need_ginv, bool need_S = true) {
     RankWs r{};
     const bool fused = need_S && fused_select(Q, G, k);
@@ -716,6 +946,8 @@ static RankWs carve(void* ws, i64 Q, i64 G, int D, int k, bool need_ginv, bool n
     char* base = ws ? (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255) : nullptr;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
     r.qn = (float*)take((size_t)Q * D * sizeof(float));
+    const i64 q_split = need_S ? qb : (Q < 256 * 64 ? Q : 256 * 64);      // queries of one cos_gemm call
+    r.qs = (bf16_t*)take(Q > 4 ? split_queries_bytes(q_split, D) : 0);
     r.ginv = (float*)take(need_ginv ? (size_t)G * sizeof(float) : 0);
     if (fused) {
         const size_t ncand = (size_t)qb * cdiv(G, RK_BN) * k;
@@ -731,23 +963,30 @@ static RankWs carve(void* ws, i64 Q, i64 G, int D, int k, bool need_ginv, bool n
     return r;
 }
 
-// resident workgroups per CU x CUs of the current device for one instantiation (cached per device)
-template <int MT, int BK, bool VEC, int FK>
-static int gemm_slots(size_t lds, int* slots_out) {
-    static int slots[MI355_MAX_DEVICES] = {0};
+// resident workgroups per CU x CUs of the current device for one kernel instantiation (cached per device by the caller)
+static int kernel_slots(const void* fn, size_t lds, int* cache, int* slots_out) {
     int dev = 0;
     MI355_CHECK_HIP(hipGetDevice(&dev));
     MI355_REQUIRE(dev >= 0 && dev < MI355_MAX_DEVICES, "rank: device ordinal %d out of range", dev);
-    if (!slots[dev]) {
-        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_cos_gemm<MT, BK, VEC, FK>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (!cache[dev]) {
+        MI355_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 0, cus = 0;
-        MI355_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_cos_gemm<MT, BK, VEC, FK>, 256, lds));
+        MI355_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds));
         MI355_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        slots[dev] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+        cache[dev] = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
     }
-    *slots_out = slots[dev];
+    *slots_out = cache[dev];
     return OK;
+}
+template <int MT, int BK, bool VEC, int FK>
+static int gemm_slots(size_t lds, int* slots_out) {
+    static int slots[MI355_MAX_DEVICES] = {0};
+    return kernel_slots((const void*)k_cos_gemm<MT, BK, VEC, FK>, lds, slots, slots_out);
+}
+template <int MT, int FK>
+static int split_slots(size_t lds, int* slots_out) {
+    static int slots[MI355_MAX_DEVICES] = {0};
+    return kernel_slots((const void*)k_cos_gemm_split<MT, FK>, lds, slots, slots_out);
 }
 
 template <int MT, int BK>
@@ -755,6 +994,21 @@ static size_t gemm_lds(bool fk) {
     const size_t stage = (size_t)2 * (64 * MT + RK_BN) * (BK + 4) * sizeof(float);
     const size_t tile = fk ? (size_t)64 * (RK_BN + 4) * sizeof(float) : 0;   // fused selection: 64 rows of the score tile at a time
     return stage > tile ? stage : tile;
+}
+template <int MT>
+static size_t split_lds(bool fk) {
+    const size_t stage = (size_t)2 * (64 * MT / 32) * 3 * 1024 + (size_t)3 * RK_BN * 16 * sizeof(float);   // A ring of 2, B ring of 3
+    const size_t tile = fk ? (size_t)64 * (RK_BN + 4) * sizeof(float) : 0;
+    return stage > tile ? stage : tile;
+}
+
+// Wave quantisation: 1564 tiles on 768 slots run as 2.04 rounds and the 28 tiles of the third round cost a whole round
+// (0.15 ms of 0.83 at Q=256 x 100k on the fp32 loop).  Whole rounds go out as 128-row tiles, the remainder as a second
+// launch of 64-row tiles (same column tiles, same k order: every score is bit-identical), which halves the tiles' length
+// and doubles their number.  Returns the number of column tiles of the main launch.
+static int whole_round_tiles(int ntx, int ny, int slots) {
+    if ((long)ntx * ny > slots && ((long)ntx * ny) % slots != 0) return (int)(((long)ntx * ny / slots) * slots / ny);
+    return ntx;
 }
 
 template <int MT, int BK, bool VEC, int FK>
@@ -765,12 +1019,7 @@ static int launch_gemm(const float* qn, const float* gal, const float* ginv, flo
     int slots = 0;
     if (int e = gemm_slots<MT, BK, VEC, FK>(lds, &slots)) return e;
     const int ntx = cdiv(G, RK_BN), ny = cdiv(Q, BM);
-    int xm = ntx;
-    // Wave quantisation: 1564 tiles on 768 slots run as 2.04 rounds and the 28 tiles of the third round cost a whole round
-    // (0.15 ms of 0.83 at Q=256 x 100k).  Whole rounds go out as 128-row tiles, the remainder as a second launch of 64-row
-    // tiles (same column tiles, same k order: every score is bit-identical), which halves the tiles' length and doubles
-    // their number.
-    if (MT == 2 && (long)ntx * ny > slots && ((long)ntx * ny) % slots != 0) xm = (int)(((long)ntx * ny / slots) * slots / ny);
+    const int xm = MT == 2 ? whole_round_tiles(ntx, ny, slots) : ntx;
     if (xm > 0) {
         hipLaunchKernelGGL((k_cos_gemm<MT, BK, VEC, FK>), dim3((unsigned)xm, (unsigned)ny), dim3(256), lds, st, qn, gal, ginv, S,
                            Q, G, D, k, cand_val, cand_idx, 0, ntx);
@@ -787,6 +1036,33 @@ static int launch_gemm(const float* qn, const float* gal, const float* ginv, flo
     return OK;
 }
 
+// split-bf16 loop: qs = the split planes of these Q queries (k_split_queries, whole 128-row tiles)
+template <int MT, int FK>
+static int launch_split(const bf16_t* qs, const float* gal, const float* ginv, float* S, int Q, i64 G, int D, int k,
+                        float* cand_val, int* cand_idx, hipStream_t st) {
+    constexpr int BM = 64 * MT;
+    const size_t lds = split_lds<MT>(FK > 0);
+    int slots = 0;
+    if (int e = split_slots<MT, FK>(lds, &slots)) return e;
+    const int ntx = cdiv(G, RK_BN), ny = cdiv(Q, BM), n_steps = cdiv(D, 16);
+    const float* zeros = reinterpret_cast<const float*>(qs + (size_t)cdiv(Q, 128) * 4 * n_steps * 3 * 512);
+    const int xm = MT == 2 ? whole_round_tiles(ntx, ny, slots) : ntx;
+    if (xm > 0) {
+        hipLaunchKernelGGL((k_cos_gemm_split<MT, FK>), dim3((unsigned)xm, (unsigned)ny), dim3(256), lds, st, qs, gal, ginv,
+                           S, Q, G, D, k, cand_val, cand_idx, 0, ntx, n_steps, zeros);
+        MI355_LAUNCH_CHECK();
+    }
+    if (xm < ntx) {
+        const size_t lds1 = split_lds<1>(FK > 0);
+        int slots1 = 0;
+        if (int e = split_slots<1, FK>(lds1, &slots1)) return e;
+        hipLaunchKernelGGL((k_cos_gemm_split<1, FK>), dim3((unsigned)(ntx - xm), (unsigned)cdiv(Q, 64)), dim3(256), lds1,
+                           st, qs, gal, ginv, S, Q, G, D, k, cand_val, cand_idx, xm, ntx, n_steps, zeros);
+        MI355_LAUNCH_CHECK();
+    }
+    return OK;
+}
+
 template <int MT, int BK, bool VEC>
 static int launch_gemm_fk(const float* qn, const float* gal, const float* ginv, float* S, int Q, i64 G, int D, int k,
                           float* cand_val, int* cand_idx, hipStream_t st) {
@@ -796,9 +1072,26 @@ static int launch_gemm_fk(const float* qn, const float* gal, const float* ginv, 
     if (k <= 4) return launch_gemm<MT, BK, VEC, 4>(qn, gal, ginv, S, Q, G, D, k, cand_val, cand_idx, st);
     return launch_gemm<MT, BK, VEC, 8>(qn, gal, ginv, S, Q, G, D, k, cand_val, cand_idx, st);
 }
+template <int MT>
+static int launch_split_fk(const bf16_t* qs, const float* gal, const float* ginv, float* S, int Q, i64 G, int D, int k,
+                           float* cand_val, int* cand_idx, hipStream_t st) {
+    if (!cand_val) return launch_split<MT, 0>(qs, gal, ginv, S, Q, G, D, 0, nullptr, nullptr, st);
+    if (k <= 1) return launch_split<MT, 1>(qs, gal, ginv, S, Q, G, D, k, cand_val, cand_idx, st);
+    if (k <= 2) return launch_split<MT, 2>(qs, gal, ginv, S, Q, G, D, k, cand_val, cand_idx, st);
+    if (k <= 4) return launch_split<MT, 4>(qs, gal, ginv, S, Q, G, D, k, cand_val, cand_idx, st);
+    return launch_split<MT, 8>(qs, gal, ginv, S, Q, G, D, k, cand_val, cand_idx, st);
+}
+
+// MI355_RANK_EXACT_F32=1 keeps the GEMM on v_mfma_f32_32x32x2_f32 (a bit-for-bit fmaf chain, 2.7x the matrix-pipe time);
+// the default is the three-way bf16 split with six products (fp32-equivalent, see split3).
+static bool rank_exact_f32() {
+    const char* e = getenv("MI355_RANK_EXACT_F32");
+    return e && e[0] && e[0] != '0';
+}
 
 // S != nullptr: score slab.  cand_val / cand_idx != nullptr: fused per-tile top-k lists [Q][cdiv(G,128)][k] (Q > 4 only).
-static int cos_gemm(const float* qn, const float* gal, const float* ginv, float* S, i64 Q, i64 G, int D,
+// qs: scratch for the split planes of these Q queries (split_queries_bytes(Q, D)); may be null for Q <= 4.
+static int cos_gemm(const float* qn, bf16_t* qs, const float* gal, const float* ginv, float* S, i64 Q, i64 G, int D,
                     hipStream_t st, int k = 0, float* cand_val = nullptr, int* cand_idx = nullptr) {
     const bool vec = vec_ok(qn, D) && vec_ok(gal, D);
     const int q = (int)Q;
@@ -811,7 +1104,14 @@ static int cos_gemm(const float* qn, const float* gal, const float* ginv, float*
         MI355_LAUNCH_CHECK();
         return OK;
     }
-    // Tile choice, measured on MI355X (tools/bench_rank.py, D = 1536): the exact-fp32 MFMA loop plateaus at 95-110 TFLOP/s
+    if (qs && vec_ok(gal, D) && !rank_exact_f32()) {
+        const int n_steps = cdiv(D, 16), n_frag = cdiv(q, 128) * 4 * n_steps;
+        hipLaunchKernelGGL(k_split_queries, dim3((unsigned)cdiv(n_frag, 4)), dim3(256), 0, st, qn, qs, q, D, n_steps, n_frag);
+        MI355_LAUNCH_CHECK();
+        if (Q > 64) return launch_split_fk<2>(qs, gal, ginv, S, q, G, D, k, cand_val, cand_idx, st);
+        return launch_split_fk<1>(qs, gal, ginv, S, q, G, D, k, cand_val, cand_idx, st);
+    }
+    // Exact-fp32 loop.  Tile choice, measured on MI355X (tools/bench_rank.py, D = 1536): it plateaus at 95-110 TFLOP/s
     // for every tile shape, so what differs is the partial last round of tiles.  128-query tiles with BK = 16 keep two
     // workgroups on a CU (41 KB of staging, 68 KB with the fused selection's score tile): a lone workgroup in the last
     // round runs at full speed, which halves the wave-quantisation loss (Q = 256, G = 100k: 0.83 ms, against 0.95 ms
@@ -874,7 +1174,7 @@ int mi355_cosine_scores(const float* queries, int64_t Q, const float* gallery, i
     const float* ginv = gallery_is_normalized ? nullptr : w.ginv;
     for (i64 qs = 0; qs < Q; qs += 256 * 64) {  // grid.y stays small
         const i64 qn = (Q - qs < 256 * 64) ? Q - qs : 256 * 64;
-        if (int e = cos_gemm(w.qn + qs * dim, gallery, ginv, out + qs * G, qn, G, dim, st)) return e;
+        if (int e = cos_gemm(w.qn + qs * dim, w.qs, gallery, ginv, out + qs * G, qn, G, dim, st)) return e;
     }
     return OK;
 }
@@ -907,13 +1207,13 @@ int mi355_rank_topk(const float* queries, int64_t Q, const float* gallery, int64
         const i64 qn = (Q - qs < qb) ? Q - qs : qb;
         if (fused) {
             // per-tile top-k straight from the GEMM's accumulators, then a merge of qn x ntiles x k candidates
-            if (int e = cos_gemm(w.qn + qs * dim, gallery, ginv, nullptr, qn, G, dim, st, k, w.cand_val, w.cand_idx)) return e;
+            if (int e = cos_gemm(w.qn + qs * dim, w.qs, gallery, ginv, nullptr, qn, G, dim, st, k, w.cand_val, w.cand_idx)) return e;
             if (int e = topk_select(w.cand_val, nullptr, qn, ntiles * k, ntiles * k, k, idx_offset, out_val + qs * k,
                                     (i64*)out_idx + qs * k, w.topk, w.topk_bytes, st, w.cand_idx))
                 return e;
             continue;
         }
-        if (int e = cos_gemm(w.qn + qs * dim, gallery, ginv, w.S, qn, G, dim, st)) return e;
+        if (int e = cos_gemm(w.qn + qs * dim, w.qs, gallery, ginv, w.S, qn, G, dim, st)) return e;
         if (int e = topk_select(w.S, nullptr, qn, G, G, k, idx_offset, out_val + qs * k, (i64*)out_idx + qs * k,
                                 w.topk, w.topk_bytes, st))
             return e;

@@ -57,6 +57,11 @@ size_t mi355_rank_workspace_bytes(int64_t Q, int64_t G, int dim, int k);
  *            mi355_l2_normalize_rows (the resident-gallery fast path), else norms are applied here
  *   out_val  [Q][k] fp32, out_idx [Q][k] int64 (index into gallery + idx_offset)
  *   idx_offset: added to every index (global row of this shard's first row)
+ * Arithmetic: fp32 in, fp32 accumulation, fp32 scores.  For Q > 4 and 16-byte aligned gallery rows the products run on the
+ * bf16 matrix pipe as a three-way split of each fp32 operand (six bf16 x bf16 products per element, each exact in the
+ * fp32 accumulator; dropped terms <= 2^-23 of a product - one fp32 rounding); the environment variable
+ * MI355_RANK_EXACT_F32=1 selects the exact fp32 MFMA (an fmaf chain) instead.  A score depends on its query row and
+ * gallery row only (not on Q, G, tiles or shards), so sharded and unsharded results are bit-identical.
  * Errors: k < 1, k > G, Q < 1, dim < 1, workspace too small. */
 int mi355_rank_topk(const float* queries, int64_t Q, const float* gallery, int64_t G, int dim,
                     int gallery_is_normalized, int k, float eps, int64_t idx_offset,
