@@ -286,8 +286,15 @@ def main():
                                "gflop_per_img": 2 * tr["macs"] / a.batch / 1e9},
             "rank_single_query": {"queries_per_s": 1.0 / t_rank1, "bound": "hbm",
                                   "gallery_stream_GBps": 4.0 * (hi - lo) * D / t_rank1 / 1e9, "peak_GBps": HBM_PEAK_GBS},
-            "rank_roofline": {"bound": "mfma-f32", "tflops": 2.0 * a.batch * (hi - lo) * D / t_rank / 1e12,
-                              "peak_tflops": 157.3},
+            # 2*Q*G*D useful flops; the default loop executes six bf16 products per fp32 product (three-way split, fp32
+            # accumulation - rank.hip), so the matrix pipe does 6x that against the dense bf16 peak; the exact fp32 MFMA
+            # loop (MI355_RANK_EXACT_F32=1) would be bounded by the 157.3 TF fp32 matrix peak
+            "rank_roofline": (lambda tf, exact: {
+                "bound": "mfma-f32" if exact else "mfma-bf16 (fp32 operands as 3 bf16 planes, 6 products, fp32 accumulate)",
+                "tflops": tf, "executed_tflops": tf if exact else 6.0 * tf,
+                "peak_tflops": 157.3 if exact else 2500.0, "frac": tf / 157.3 if exact else 6.0 * tf / 2500.0,
+                "vs_fp32_mfma_peak": tf / 157.3})(2.0 * a.batch * (hi - lo) * D / t_rank / 1e12,
+                                                  os.environ.get("MI355_RANK_EXACT_F32", "0") not in ("", "0")),
             "roofline": roofline,
         }
         result.update(side)

@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void k_cos_gemm(const float* __restrict__ Qn, 
 // No load in the loop has a register destination, so the only waits are the ones written here: ONE vmcnt(2) per k-step
 // (the counter retires in order: everything but this iteration's two B pieces - issued last - has landed) and one
 // LDS-only barrier.  (With register-staged B loads hipcc drained vmcnt(0) before every store to LDS.)
-// LDS: 2 x MT x 6 KB (A) + 3 x 8 KB (B) = 48 KB at MT = 2 -> three workgroups per CU.
+// LDS: 2 x 12 KB (A) + 3 x 8 KB (B) = 48 KB at MT = 2 -> three workgroups per CU; 3 x 6 + 24 = 42 KB at MT = 1.
 // =====================================================================================
 template <int MT, int FK>
 __global__ __launch_bounds__(256, 3) void k_cos_gemm_split(const bf16_t* __restrict__ Qs, const float* __restrict__ Gal,
@@ -424,8 +424,12 @@ __global__ __launch_bounds__(256, 3) void k_cos_gemm_split(const bf16_t* __restr
     constexpr int A_PIECES = (BM / 32) * 3;           // 1 KB pieces per stage
     constexpr int B_STAGE = RK_BN * BK;               // floats per stage (8 KB)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    bf16_t* As = reinterpret_cast<bf16_t*>(smem);                       // [2][BM/32][3][512]
-    float* Bs = smem + (2 * A_STAGE * 2) / 4;                           // [3][128][16], chunks swizzled
+    bf16_t* As = reinterpret_cast<bf16_t*>(smem);                       // [A_RING][BM/32][3][512]
+    // A ring: 2 stages at MT = 2 (the pieces come from L2 one k-step ahead; a third stage would cost the third workgroup per
+    // CU), 3 stages at MT = 1 (two k-steps ahead: the 64-row tiles are the tail launch and the small-Q shapes, few
+    // workgroups per CU with nothing else to hide a piece's latency behind)
+    constexpr int A_RING = MT == 1 ? 3 : 2;
+    float* Bs = smem + (A_RING * A_STAGE * 2) / 4;                      // [3][128][16], chunks swizzled
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -523,19 +527,30 @@ __global__ __launch_bounds__(256, 3) void k_cos_gemm_split(const bf16_t* __restr
     };
 
     dma_a(0, 0);
+    if (A_RING == 3 && n_steps > 1) dma_a(1, 1);
     dma_b(0, 0);
     dma_b(1, BK);                      // (zeros past D)
     __syncthreads();                   // drains vmcnt: everything has landed
 
-    int bs_cur = 0, bs_far = 2;        // B stage of k-step t / of k-step t + 2
+    int bs_cur = 0, bs_far = 2;        // B stage of k-step t / of k-step t + 2 (and, at A_RING == 3, the A stages)
     for (int t = 0; t < n_steps; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < n_steps) dma_a(buf ^ 1, t + 1);          // everybody left these buffers at the previous barrier
-        __builtin_amdgcn_sched_barrier(0);                   // (the count below needs the A pieces issued BEFORE the B pieces)
+        if constexpr (A_RING == 2) {
+            if (t + 1 < n_steps) dma_a((t & 1) ^ 1, t + 1);  // everybody left these buffers at the previous barrier
+        } else {
+            if (t + 2 < n_steps) dma_a(bs_far, t + 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);                   // (the counts below need the A pieces issued BEFORE the B pieces)
         dma_b(bs_far, (t + 2) * BK);
         __builtin_amdgcn_sched_barrier(0);
-        compute(buf, bs_cur);
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // A(t+1) and B(t+1) have landed; B(t+2) stays in flight
+        compute(A_RING == 2 ? (t & 1) : bs_cur, bs_cur);
+        if constexpr (A_RING == 2) {
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); // A(t+1) and B(t+1) have landed; B(t+2) stays in flight
+        } else {
+            // A(t+2) (two pieces from waves 0 and 1, one from waves 2 and 3; none at the end) and B(t+2) stay in flight
+            if (t + 2 >= n_steps) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (swave < A_PIECES % 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -997,7 +1012,7 @@ static size_t gemm_lds(bool fk) {
 }
 template <int MT>
 static size_t split_lds(bool fk) {
-    const size_t stage = (size_t)2 * (64 * MT / 32) * 3 * 1024 + (size_t)3 * RK_BN * 16 * sizeof(float);   // A ring of 2, B ring of 3
+    const size_t stage = (size_t)(MT == 1 ? 3 : 2) * (64 * MT / 32) * 3 * 1024 + (size_t)3 * RK_BN * 16 * sizeof(float);   // A ring of 2 (3 at MT = 1), B ring of 3
     const size_t tile = fk ? (size_t)64 * (RK_BN + 4) * sizeof(float) : 0;
     return stage > tile ? stage : tile;
 }
