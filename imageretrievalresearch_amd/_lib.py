@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355_retrieval.so")
+# MI355_LIB_PATH: another build of the same library (developer A/B runs of two kernel variants on one box)
+LIB_PATH = os.environ.get("MI355_LIB_PATH") or os.path.join(_HERE, "libmi355_retrieval.so")
 
 c_f32p = C.POINTER(C.c_float)
 c_i64p = C.POINTER(C.c_int64)

@@ -499,24 +499,26 @@ __global__ __launch_bounds__(256, 3) void k_cos_gemm_split(const bf16_t* __restr
         const float* b = Bs + bstage * B_STAGE;
         bf16x8 af[MT][3];
         u32x4 bh[2], bm[2], bl[2];
+        f32x4 v0[2], v1[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            v0[j] = *reinterpret_cast<const f32x4*>(b + b_off[j][0]);
+            v1[j] = *reinterpret_cast<const f32x4*>(b + b_off[j][1]);
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(a + (i * 3 + p) * 512);
+        split3(v0[0], v1[0], bh[0], bm[0], bl[0]);
+        // Per fragment j: six products for each of the MT row blocks, smallest terms first (the order is the same for every
+        // (query, gallery row) pair wherever its tile lies).  The split of fragment 1 is issued in the gaps of fragment 0's
+        // MFMAs (an MFMA holds the vector issue for 8 of its 32 cycles): sched_group_barrier pins "1 MFMA, 4 VALU" groups.
+        auto products = [&](int j) {
+            const bf16x8 gh = *reinterpret_cast<const bf16x8*>(&bh[j]);
+            const bf16x8 gm = *reinterpret_cast<const bf16x8*>(&bm[j]);
+            const bf16x8 gl = *reinterpret_cast<const bf16x8*>(&bl[j]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(b + b_off[j][0]);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(b + b_off[j][1]);
-            split3(v0, v1, bh[j], bm[j], bl[j]);
-        }
-        // smallest terms first; the order is the same for every (query, gallery row) pair wherever its tile lies
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const bf16x8 gh = *reinterpret_cast<const bf16x8*>(&bh[j]);
-                const bf16x8 gm = *reinterpret_cast<const bf16x8*>(&bm[j]);
-                const bf16x8 gl = *reinterpret_cast<const bf16x8*>(&bl[j]);
+            for (int i = 0; i < MT; ++i) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], gh, acc[i][j], 0, 0, 0);   // l * h'
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], gl, acc[i][j], 0, 0, 0);   // h * l'
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], gm, acc[i][j], 0, 0, 0);   // m * m'
@@ -524,6 +526,15 @@ __global__ __launch_bounds__(256, 3) void k_cos_gemm_split(const bf16_t* __restr
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], gm, acc[i][j], 0, 0, 0);   // h * m'
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], gh, acc[i][j], 0, 0, 0);   // h * h'
             }
+        };
+        split3(v0[1], v1[1], bh[1], bm[1], bl[1]);
+        products(0);
+#pragma unroll
+        for (int g = 0; g < 6 * MT; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // four VALU (of fragment 1's split)
+        }
+        products(1);
     };
 
     dma_a(0, 0);
