@@ -10,6 +10,16 @@ namespace mi355 {
 
 // ---- error plumbing: every C-ABI entry returns 0 on success, nonzero + mi355_last_error() text.
 void set_error(const char* fmt, ...);
+// roctx ranges around executor ops / rank phases (api.cpp; no-ops unless enabled and the marker library is present)
+void roctx_enable(bool on);
+bool roctx_active();
+void roctx_push(const char* label);
+void roctx_pop();
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char* label) : on(roctx_active()) { if (on) roctx_push(label); }
+    ~RoctxRange() { if (on) roctx_pop(); }
+};
 enum { OK = 0, ERR_ARG = 1, ERR_HIP = 2, ERR_STATE = 3, ERR_UNSUPPORTED = 4 };
 
 #define MI355_CHECK_HIP(expr)                                                              \

@@ -403,6 +403,18 @@ static int exec_fused(ExecCtx& cx, const Op& g, const Op& d) {
     return launch_fused_band(a, cx.nb, d.k, d.stride, cx.st);
 }
 
+// roctx range label of one executor launch (same wording as mi355_model_profile_ops)
+static void op_range_label(const Op& op, int H, int W, int in_h, int in_w, const char* how, char* lab, size_t n) {
+    switch (op.kind) {
+        case OP_STEM: snprintf(lab, n, "embed/%sstem 3->%d @%dx%d", how, op.cout_real, conv_out(H, 3, 2), conv_out(W, 3, 2)); break;
+        case OP_GEMM: snprintf(lab, n, "embed/%spw %d->%d @%dx%d%s%s", how, op.cin_real, op.cout_real, in_h, in_w,
+                               op.use_gate ? " gate" : "", op.res != SLOT_NONE ? " res" : ""); break;
+        case OP_DW: snprintf(lab, n, "embed/%sdw k%d s%d C%d @%dx%d", how, op.k, op.stride, op.cin_real, in_h, in_w); break;
+        case OP_SE: snprintf(lab, n, "embed/%sse C%d rd%d", how, op.cin_real, op.rd); break;
+        default: snprintf(lab, n, "embed/%sop%d C%d->%d t%d", how, (int)op.kind, op.cin_real, op.cout_real, op.tokens_h); break;
+    }
+}
+
 static int run_backbone(ExecCtx& cx, size_t op_begin = 0, size_t op_end = (size_t)-1) {
     mi355_model* m = cx.m;
     // NOTE: slot dims for DW/SE depend on walk order; plan_slots() left the LAST writer's dims in each
@@ -442,11 +454,17 @@ static int run_backbone(ExecCtx& cx, size_t op_begin = 0, size_t op_end = (size_
             MI355_CHECK_HIP(hipEventCreate(&e1));
             MI355_CHECK_HIP(hipEventRecord(e0, cx.st));
         }
-        if (block) {
-            if (int e = exec_block(cx, oi)) return e;
-        } else if (fused) {
-            if (int e = exec_fused(cx, op, m->def.ops[oi + 1])) return e;
-        } else if (int e = exec_op(cx, op)) return e;
+        {
+            char lab[192] = "";
+            if (roctx_active())
+                op_range_label(op, cx.H, cx.W, in_h, in_w, block ? "block: " : (fused ? "fused: " : ""), lab, sizeof lab);
+            RoctxRange range(lab);
+            if (block) {
+                if (int e = exec_block(cx, oi)) return e;
+            } else if (fused) {
+                if (int e = exec_fused(cx, op, m->def.ops[oi + 1])) return e;
+            } else if (int e = exec_op(cx, op)) return e;
+        }
         if (m->profile) {
             MI355_CHECK_HIP(hipEventRecord(e1, cx.st));
             m->prof_events.push_back({op_index, {e0, e1}});
@@ -772,6 +790,7 @@ int mi355_model_set_option(mi355_model_t m, const char* key, int64_t value) {
     else if (k == "fuse_block_min_batch") m->fuse_block_min_batch = (int)value;
     else if (k == "block_stamps") m->block_stamps = value != 0;
     else if (k == "block_norot") m->block_norot = (int)value;
+    else if (k == "roctx") roctx_enable(value != 0);   // process-wide: ranges around every executor op and rank phase
     else if (k == "profile") {
         m->profile = value != 0;
         for (int i = 0; i < PK_COUNT; ++i) { m->prof_ms[i] = 0; m->prof_launches[i] = 0; }

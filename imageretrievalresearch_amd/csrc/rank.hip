@@ -1217,13 +1217,16 @@ int mi355_rank_topk(const float* queries, int64_t Q, const float* gallery, int64
     MI355_REQUIRE(workspace && workspace_bytes >= w.total, "rank_topk: workspace %zu < %zu bytes", workspace_bytes,
                   w.total);
     const int vq = vec_ok(queries, dim) && vec_ok(w.qn, dim);
-    hipLaunchKernelGGL((k_row_norm<true>), dim3((unsigned)cdiv(Q, 4)), dim3(256), 0, st, queries, w.qn,
-                       (float*)nullptr, (i64)Q, dim, eps, vq);
-    MI355_LAUNCH_CHECK();
-    if (!gallery_is_normalized) {
-        hipLaunchKernelGGL((k_row_norm<false>), dim3((unsigned)cdiv(G, 4)), dim3(256), 0, st, gallery,
-                           (float*)nullptr, w.ginv, (i64)G, dim, eps, vec_ok(gallery, dim));
+    {
+        RoctxRange range("rank/normalize");
+        hipLaunchKernelGGL((k_row_norm<true>), dim3((unsigned)cdiv(Q, 4)), dim3(256), 0, st, queries, w.qn,
+                           (float*)nullptr, (i64)Q, dim, eps, vq);
         MI355_LAUNCH_CHECK();
+        if (!gallery_is_normalized) {
+            hipLaunchKernelGGL((k_row_norm<false>), dim3((unsigned)cdiv(G, 4)), dim3(256), 0, st, gallery,
+                               (float*)nullptr, w.ginv, (i64)G, dim, eps, vec_ok(gallery, dim));
+            MI355_LAUNCH_CHECK();
+        }
     }
     const float* ginv = gallery_is_normalized ? nullptr : w.ginv;
     const i64 qb = query_block(Q, G, k);
@@ -1233,7 +1236,11 @@ int mi355_rank_topk(const float* queries, int64_t Q, const float* gallery, int64
         const i64 qn = (Q - qs < qb) ? Q - qs : qb;
         if (fused) {
             // per-tile top-k straight from the GEMM's accumulators, then a merge of qn x ntiles x k candidates
-            if (int e = cos_gemm(w.qn + qs * dim, w.qs, gallery, ginv, nullptr, qn, G, dim, st, k, w.cand_val, w.cand_idx)) return e;
+            {
+                RoctxRange range("rank/cosine gemm + per-tile top-k");
+                if (int e = cos_gemm(w.qn + qs * dim, w.qs, gallery, ginv, nullptr, qn, G, dim, st, k, w.cand_val, w.cand_idx)) return e;
+            }
+            RoctxRange range("rank/merge candidates");
             if (int e = topk_select(w.cand_val, nullptr, qn, ntiles * k, ntiles * k, k, idx_offset, out_val + qs * k,
                                     (i64*)out_idx + qs * k, w.topk, w.topk_bytes, st, w.cand_idx))
                 return e;
