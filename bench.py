@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--gallery", type=int, default=GALLERY_ROWS)
     ap.add_argument("--microbatch", type=int, default=int(os.environ.get("MI355_MICROBATCH", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=2, choices=(1, 2),
+                    help="2: embed on one HIP stream, rank on a second (rank of batch i beside embed of batch i+1); 1: one stream")
     ap.add_argument("--model", default="efficientnet_b3a")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
@@ -133,6 +135,9 @@ def main():
     s_embed, s_rank = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
 
     def step():
+        if a.streams == 1:
+            with torch.cuda.stream(s_embed):
+                return gal.search(model(x), TOPK)
         with torch.cuda.stream(s_embed):
             emb = model(x)
             done = torch.cuda.Event()
@@ -278,7 +283,7 @@ def main():
                                    f"{a.batch * world} embeddings vs {a.gallery}x{D} fp32 gallery "
                                    f"(row-sharded over {world} GPU)", "batch_per_gpu": a.batch,
                        "gallery_rows": a.gallery, "dim": D, "k": TOPK, "microbatch": a.microbatch,
-                       "parallelism": f"dp{world} + row-sharded gallery", "streams": "embed || rank (2 HIP streams)"},
+                       "parallelism": f"dp{world} + row-sharded gallery", "streams": "embed || rank (2 HIP streams)" if a.streams == 2 else "one HIP stream"},
             "embed_images_per_s_1gpu": a.batch / t_embed,
             "rank_queries_per_s_1gpu_shard": a.batch / t_rank,
             "embed_roofline": {"algorithmic_GBps": embed_gbs, "frac_of_8TBps": embed_gbs / HBM_PEAK_GBS,

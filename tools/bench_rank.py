@@ -12,7 +12,7 @@ if os.environ.get("CASES"):
 for Q, G in cases:
     q = M.synth_fill(Q * 1536, 13, synth.NORMAL, dev).view(Q, 1536)
     g = M.l2_normalize_rows(M.synth_fill(G * 1536, 5, synth.NORMAL, dev).view(G, 1536))
-    for _ in range(3): M.cosine_topk(q, g, 3, gallery_is_normalized=True)
+    for _ in range(25): M.cosine_topk(q, g, 3, gallery_is_normalized=True)   # (the first ~10 calls of a process run 15 % slower)
     torch.cuda.synchronize(); t = time.perf_counter(); n = 20
     for _ in range(n): M.cosine_topk(q, g, 3, gallery_is_normalized=True)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
