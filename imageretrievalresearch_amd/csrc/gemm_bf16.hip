@@ -287,13 +287,24 @@ __device__ __forceinline__ void glds16(const bf16_t* gsrc, bf16_t* lds_dst) {
 // waves then split M only (32 rows x all 128 columns each) so that no A fragment is gated twice.
 // K does not have to be a multiple of 64: lanes whose 16-byte chunk lies past K (or past row M / N) read from a
 // zero page instead (g.zeros), so no garbage ever enters the accumulation.
-template <bool GATED, bool KTAIL>
-__global__ __launch_bounds__(256) void k_gemm_big(const GemmArgs g, const int n_tiles, const int nwg) {
+// BKT = K depth of a stage.  64: the form above (64 KB ring, 67.6 KB with the fp32 residual tile: two workgroups per CU).
+// 32 (ungated only): a 32 KB ring and an epilogue that passes the tile through LDS in two 64-row halves - 34.8 KB, FOUR
+// workgroups per CU.  For the short-K, wide-N layers (Swin's K = 128 / 256 linears: 2 - 8 k-steps, outputs 3 - 4x the
+// inputs) a workgroup's life is dominated by its epilogue: its slot stays occupied until the L2 has acknowledged the
+// stores (measured: 128->512 @56x56 takes 202 us, 86 us with the stores removed, and the same 411 MB written by a
+// store-only kernel take 67 us), so what helps is more workgroups per CU to wait beside each other.
+template <bool GATED, bool KTAIL, int BKT = 64>
+__global__ __launch_bounds__(256, BKT == 32 ? 3 : 1) void k_gemm_big(const GemmArgs g, const int n_tiles, const int nwg) {
     constexpr int MI = GATED ? 2 : 4;      // 16-row sub-tiles per wave
     constexpr int NI = GATED ? 8 : 4;      // 16-column sub-tiles per wave
+    static_assert(BKT == 64 || (BKT == 32 && !GATED), "stage depths");
+    constexpr int PPW = BKT / 16;                  // 1 KB pieces per operand per wave per stage (4 or 2)
+    constexpr int RPP = 512 / BKT;                 // tile rows per piece (8 or 16)
+    constexpr int CPRW = BKT / 8;                  // 16-byte chunks per tile row (8 or 4)
     extern __shared__ __attribute__((aligned(16))) bf16_t bsm[];
-    bf16_t* As = bsm;                              // [2][128*64]
-    bf16_t* Ws = bsm + 2 * BG_BM * BG_BK;          // [2][128*64]
+    bf16_t* As = bsm;                              // [2][128*BKT]
+    bf16_t* Ws = bsm + 2 * BG_BM * BKT;            // [2][128*BKT]
+    auto swz = [](int row) { return BKT == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int logical;
     {
@@ -305,15 +316,15 @@ __global__ __launch_bounds__(256) void k_gemm_big(const GemmArgs g, const int n_
     const int m0 = mb * BG_BM, n0 = nb * BG_BN;
     const int Npad = (g.N + 15) & ~15;
 
-    // staging: wave w issues 4 A pieces and 4 W pieces per tile; piece p covers tile rows p*8 .. p*8+7
-    const bf16_t* a_src[4];
-    const bf16_t* w_src[4];
-    int k_off[4];
-    bool a_ok[4], w_ok[4];
+    // staging: wave w issues PPW A pieces and PPW W pieces per stage; piece p covers tile rows p*RPP .. p*RPP+RPP-1
+    const bf16_t* a_src[PPW];
+    const bf16_t* w_src[PPW];
+    int k_off[PPW];
+    bool a_ok[PPW], w_ok[PPW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + (lane >> 3);
-        const int lchunk = (lane & 7) ^ ((row >> 1) & 7);
+    for (int i = 0; i < PPW; ++i) {
+        const int row = (wave * PPW + i) * RPP + lane / CPRW;
+        const int lchunk = (lane % CPRW) ^ swz(row);
         k_off[i] = lchunk * 8;
         a_ok[i] = (m0 + row) < g.M;
         w_ok[i] = (n0 + row) < Npad;
@@ -322,14 +333,14 @@ __global__ __launch_bounds__(256) void k_gemm_big(const GemmArgs g, const int n_
     }
     auto stage = [&](int buf, int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = wave * 4 + i;            // wave-uniform
-            // KTAIL = false: K and ldw are multiples of 64 and out-of-range rows were clamped to row 0 (finite data,
+        for (int i = 0; i < PPW; ++i) {
+            const int piece = wave * PPW + i;          // wave-uniform
+            // KTAIL = false: K and ldw are multiples of the stage depth and out-of-range rows were clamped to row 0 (finite data,
             // never stored), so the loop has no selects; KTAIL = true routes every out-of-range chunk to the zero page
             const bf16_t* pa = KTAIL ? ((a_ok[i] && k0 + k_off[i] < g.K) ? a_src[i] + k0 : g.zeros) : a_src[i] + k0;
             const bf16_t* pw = KTAIL ? ((w_ok[i] && k0 + k_off[i] < g.ldw) ? w_src[i] + k0 : g.zeros) : w_src[i] + k0;
-            glds16(pa, As + buf * BG_BM * BG_BK + piece * 512);
-            glds16(pw, Ws + buf * BG_BN * BG_BK + piece * 512);
+            glds16(pa, As + buf * BG_BM * BKT + piece * 512);
+            glds16(pw, Ws + buf * BG_BN * BKT + piece * 512);
         }
     };
 
@@ -366,13 +377,13 @@ __global__ __launch_bounds__(256) void k_gemm_big(const GemmArgs g, const int n_
             }
     };
 
-    const int nt = (g.K + BG_BK - 1) / BG_BK;
+    const int nt = (g.K + BKT - 1) / BKT;
     stage(0, 0);
     if (GATED && g.gate) load_gate(0);
     __syncthreads();   // the fence drains vmcnt for the LDS-DMA as well
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nt) stage(buf ^ 1, (t + 1) * BG_BK);
+        if (t + 1 < nt) stage(buf ^ 1, (t + 1) * BKT);
         f32x4 gcur[MI][2][2];
         if (GATED && g.gate) {
 #pragma unroll
@@ -381,15 +392,15 @@ __global__ __launch_bounds__(256) void k_gemm_big(const GemmArgs g, const int n_
                 for (int ks = 0; ks < 2; ++ks) { gcur[mi][ks][0] = gnext[mi][ks][0]; gcur[mi][ks][1] = gnext[mi][ks][1]; }
             if (t + 1 < nt) load_gate(t + 1);
         }
-        const bf16_t* as = As + buf * BG_BM * BG_BK;
-        const bf16_t* ws = Ws + buf * BG_BN * BG_BK;
+        const bf16_t* as = As + buf * BG_BM * BKT;
+        const bf16_t* ws = Ws + buf * BG_BN * BKT;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BKT / 32; ++ks) {
             bf16x8 af[MI], wf[NI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int ra = row_base + i * 16 + fr;
-                u32x4 v = *reinterpret_cast<const u32x4*>(&as[ra * 64 + (((ks * 4 + fq) ^ ((ra >> 1) & 7)) << 3)]);
+                u32x4 v = *reinterpret_cast<const u32x4*>(&as[ra * BKT + (((ks * 4 + fq) ^ swz(ra)) << 3)]);
                 if (GATED) {
                     if (g.gate) v = gate_chunk_regs(v, gcur[i][ks][0], gcur[i][ks][1], g.a_relu6);   // zeros past K
                     else if (g.a_relu6) v = relu6_chunk(v);
@@ -399,7 +410,7 @@ __global__ __launch_bounds__(256) void k_gemm_big(const GemmArgs g, const int n_
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int rw = col_base + i * 16 + fr;
-                wf[i] = *reinterpret_cast<const bf16x8*>(&ws[rw * 64 + (((ks * 4 + fq) ^ ((rw >> 1) & 7)) << 3)]);
+                wf[i] = *reinterpret_cast<const bf16x8*>(&ws[rw * BKT + (((ks * 4 + fq) ^ swz(rw)) << 3)]);
             }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
@@ -455,32 +466,39 @@ _Pragma("unroll")
         // residual layers (Swin proj / fc2 update the stream in place): stage the fp32 tile so the add happens
         // before the single bf16 rounding, then stream rows with 16-byte residual loads and stores.
         constexpr int FLD = BG_BN + 4;
-        float* Cf = reinterpret_cast<float*>(bsm);   // [128][132] fp32 = 67.6 KB
+        float* Cf = reinterpret_cast<float*>(bsm);   // [128][132] fp32 = 67.6 KB; BKT = 32: [64][132] = 33.8 KB, two passes
+        constexpr int HALVES = BKT == 32 ? 2 : 1, HROWS = BG_BM / HALVES;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int ml = row_base + mi * 16 + fr;
+        for (int h = 0; h < HALVES; ++h) {
+            if (HALVES == 1 || row_base / HROWS == h) {      // (ungated: a wave's 64 rows lie in one half)
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int nl = col_base + ni * 16 + fq * 4;
-                *reinterpret_cast<f32x4*>(&Cf[ml * FLD + nl]) = acc[ni][mi];
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int ml = row_base + mi * 16 + fr - h * HROWS;
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const int nl = col_base + ni * 16 + fq * 4;
+                        *reinterpret_cast<f32x4*>(&Cf[ml * FLD + nl]) = acc[ni][mi];
+                    }
+                }
             }
-        }
-        __syncthreads();
-        constexpr int CPR = BG_BN / 8;
-        for (int id = tid; id < BG_BM * CPR; id += 256) {
-            const int row = id / CPR, c = id - row * CPR;
-            const int m = m0 + row, n = n0 + c * 8;
-            if (m < g.M && n < g.N) {
-                const f32x4 c0 = *reinterpret_cast<const f32x4*>(&Cf[row * FLD + c * 8]);
-                const f32x4 c1 = *reinterpret_cast<const f32x4*>(&Cf[row * FLD + c * 8 + 4]);
-                const u32x4 rr = *reinterpret_cast<const u32x4*>(g.res + (size_t)m * g.ldr + n);
-                u32x4 o;
-                o.x = pack2bf(c0.x + lo_bf(rr.x), c0.y + hi_bf(rr.x));
-                o.y = pack2bf(c0.z + lo_bf(rr.y), c0.w + hi_bf(rr.y));
-                o.z = pack2bf(c1.x + lo_bf(rr.z), c1.y + hi_bf(rr.z));
-                o.w = pack2bf(c1.z + lo_bf(rr.w), c1.w + hi_bf(rr.w));
-                *reinterpret_cast<u32x4*>((bf16_t*)g.out + (size_t)m * g.ldo + n) = o;
+            __syncthreads();
+            constexpr int CPR = BG_BN / 8;
+            for (int id = tid; id < HROWS * CPR; id += 256) {
+                const int row = id / CPR, c = id - row * CPR;
+                const int m = m0 + h * HROWS + row, n = n0 + c * 8;
+                if (m < g.M && n < g.N) {
+                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(&Cf[row * FLD + c * 8]);
+                    const f32x4 c1 = *reinterpret_cast<const f32x4*>(&Cf[row * FLD + c * 8 + 4]);
+                    const u32x4 rr = *reinterpret_cast<const u32x4*>(g.res + (size_t)m * g.ldr + n);
+                    u32x4 o;
+                    o.x = pack2bf(c0.x + lo_bf(rr.x), c0.y + hi_bf(rr.x));
+                    o.y = pack2bf(c0.z + lo_bf(rr.y), c0.w + hi_bf(rr.y));
+                    o.z = pack2bf(c1.x + lo_bf(rr.z), c1.y + hi_bf(rr.z));
+                    o.w = pack2bf(c1.z + lo_bf(rr.w), c1.w + hi_bf(rr.w));
+                    *reinterpret_cast<u32x4*>((bf16_t*)g.out + (size_t)m * g.ldo + n) = o;
+                }
             }
+            if (h + 1 < HALVES) __syncthreads();
         }
         return;
     }
@@ -519,18 +537,19 @@ _Pragma("unroll")
     }
 }
 
-template <bool GATED, bool KTAIL>
+template <bool GATED, bool KTAIL, int BKT = 64>
 static int launch_big(const GemmArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)BG_BM * (BG_BN + 4) * 4;   // 67.6 KB: fp32 epilogue tile (>= the 64 KB of stage buffers)
+    // 67.6 KB: fp32 epilogue tile (>= the 64 KB of stage buffers); BKT = 32: 34.8 KB bf16 tile (>= 33.8 KB half fp32 tile, 32 KB ring)
+    const size_t lds = BKT == 64 ? (size_t)BG_BM * (BG_BN + 4) * 4 : (size_t)BG_BM * (BG_BN + 8) * 2;
     static bool attr_done[MI355_MAX_DEVICES] = {false};   // per device
     if (first_time_on_this_device(attr_done)) {
-        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_big<GATED, KTAIL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemm_big<GATED, KTAIL, BKT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds));
     }
     const int n_tiles = cdiv(a.N, BG_BN), m_tiles = cdiv(a.M, BG_BM);
     const long nwg = (long)n_tiles * m_tiles;
     MI355_REQUIRE(nwg < (1l << 31), "gemm: grid too large");
-    hipLaunchKernelGGL((k_gemm_big<GATED, KTAIL>), dim3((unsigned)nwg), dim3(256), lds, st, a, n_tiles, (int)nwg);
+    hipLaunchKernelGGL((k_gemm_big<GATED, KTAIL, BKT>), dim3((unsigned)nwg), dim3(256), lds, st, a, n_tiles, (int)nwg);
     MI355_LAUNCH_CHECK();
     return OK;
 }
@@ -1055,7 +1074,12 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t st) {
         const bool fits = a.N <= BG_BN ? a.N >= 72 : (long)a.N * 16 >= (long)cdiv(a.N, BG_BN) * BG_BN * 10;
         const bool ktail = (a.K % 64 != 0) || (a.ldw % 64 != 0);
         if ((a.gate || a.a_relu6) && fits) return ktail ? launch_big<true, true>(a, st) : launch_big<true, false>(a, st);
-        if (!a.gate && !a.a_relu6 && a.N >= 96) return ktail ? launch_big<false, true>(a, st) : launch_big<false, false>(a, st);
+        if (!a.gate && !a.a_relu6 && a.N >= 96) {
+            // short K, outputs at least as wide as the inputs: four small-ring workgroups per CU (see k_gemm_big)
+            static const int short_k = getenv("MI355_GEMM_SHORT_K") ? atoi(getenv("MI355_GEMM_SHORT_K")) : 128;
+            if (!ktail && a.K <= short_k && a.N >= a.K && a.M >= 32768) return launch_big<false, false, 32>(a, st);
+            return ktail ? launch_big<false, true>(a, st) : launch_big<false, false>(a, st);
+        }
     }
     // small-K layers are pure streaming (one or two K tiles): narrower tiles keep 4+ waves per SIMD resident
     static const int use_stream = getenv("MI355_GEMM_STREAM") ? atoi(getenv("MI355_GEMM_STREAM")) : 1;
