@@ -85,3 +85,30 @@ def test_swin_full_batch_properties_b128():
     perm = torch.from_numpy(np.random.RandomState(7).permutation(B)).to(DEV)
     assert torch.equal(model(x[perm].contiguous()), a[perm])
     assert rel(model(x[:2].contiguous()).cpu(), a[:2].cpu()) < 5e-3
+
+
+@pytest.mark.parametrize("N,act", [(128, 0), (384, 4), (520, 1)])
+def test_short_k_gemm_instantiation_matches_the_default_one(N, act):
+    """K = 128, N >= K, M >= 32768 selects k_gemm_big<.., 32> (32-deep stages, three workgroups per CU, epilogue tile in
+    halves); the same rows in a smaller problem take the 64-deep form.  Same k order, so the results must be bit-identical,
+    and both must sit within bf16 rounding of the fp32 product (ragged last row tile, ragged last column tile)."""
+    from imageretrievalresearch_amd._lib import lib, check, stream_ptr
+    K, Mbig, Msmall = 128, 32768 + 77, 4096
+    g = torch.Generator(device="cpu").manual_seed(5)
+    A = (torch.randn(Mbig, K, generator=g) * 0.5).to(DEV).bfloat16()
+    Np = (N + 15) // 16 * 16
+    W = torch.zeros(Np, K, device=DEV, dtype=torch.bfloat16)
+    W[:N] = (torch.randn(N, K, generator=g) * 0.1).to(DEV).bfloat16()
+    bias = torch.zeros(Np, device=DEV)
+    bias[:N] = torch.randn(N, generator=g).to(DEV) * 0.1
+
+    def run(rows):
+        out = torch.empty(rows, N, device=DEV, dtype=torch.bfloat16)
+        check(lib().mi355_gemm_bf16(A.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr(), rows, N, K, K, act, stream_ptr(DEV)))
+        return out
+    big, small = run(Mbig), run(Msmall)
+    assert torch.equal(big[:Msmall], small)
+    ref = A.float() @ W[:N].float().t() + bias[:N]
+    ref = {0: lambda t: t, 1: torch.nn.functional.silu, 4: torch.nn.functional.gelu}[act](ref)
+    err = (big.float() - ref).abs().max().item()
+    assert err < 2.0 ** -7 * max(1.0, ref.abs().max().item()), err      # one bf16 rounding of the output
