@@ -304,7 +304,11 @@ __global__ __launch_bounds__(256, BKT == 32 ? 3 : 1) void k_gemm_big(const GemmA
     extern __shared__ __attribute__((aligned(16))) bf16_t bsm[];
     bf16_t* As = bsm;                              // [2][128*BKT]
     bf16_t* Ws = bsm + 2 * BG_BM * BKT;            // [2][128*BKT]
-    auto swz = [](int row) { return BKT == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
+    // chunk swizzle (applied to the DMA's source address and to the fragment reads alike).  ds_read_b128 is serviced in the lane
+    // groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: for 64-byte rows the 16-byte slot is 4*(row%4) + (chunk ^ swz), and
+    // swz = -(row/4) mod 4 is what makes the four lanes of a group that share row%4 land on four different slots (the
+    // obvious (row/4)%4 is a 2-way conflict: PMC SQ_LDS_BANK_CONFLICT was 47 % of the LDS cycles of this kernel)
+    auto swz = [](int row) { return BKT == 64 ? ((row >> 1) & 7) : ((0 - (row >> 2)) & 3); };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int logical;
     {
