@@ -346,3 +346,19 @@ def test_each_block_on_the_oracles_own_input(setup, B):
         assert e < TOL_BLOCK_ISOLATED, f"{prev} -> {cur} at B={B}: rel L2 {e:.3e}"
     model.enable_taps(False)
     print(f"B={B}: worst isolated block {worst}")
+
+
+def test_roctx_ranges_do_not_change_results(setup):
+    """set_option("roctx", 1) wraps every executor launch and rank phase in a roctxRangePush/Pop pair (marker library
+    looked up at run time, no-ops without it): results must be unaffected and the switch must turn off again."""
+    sd, model = setup
+    x = torch.from_numpy(images(91, 4)).to(DEV)
+    want = model(x)
+    wv, wi = M.cosine_topk(want, want, 2)
+    model.set_option("roctx", 1)
+    try:
+        got = model(x)
+        v, i = M.cosine_topk(got, got, 2)
+    finally:
+        model.set_option("roctx", 0)
+    assert torch.equal(got, want) and torch.equal(v, wv) and torch.equal(i, wi)
