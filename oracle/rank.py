@@ -128,16 +128,6 @@ def distinct_class_top3(inds: np.ndarray, vals: np.ndarray, gallery_cls: np.ndar
     return oc, oi, ov
 
 
-def score_boost(score: np.ndarray, eps: float, alpha: float, mode: str) -> np.ndarray:
-    """utils/score_booster.py:21-37."""
-    score = np.asarray(score, np.float32)
-    if mode == "for_pos":
-        return ((score + np.float32(eps)) / np.float32(eps + alpha)).astype(np.float32)
-    if mode == "for_neg":
-        return np.abs((score + np.float32(alpha / eps)) / np.float32(2 * eps)).astype(np.float32)
-    raise ValueError(mode)
-
-
 def score_boost(score: np.ndarray, eps: float, alpha: float, threshold: float = 0.0, mode: str = "threshold") -> np.ndarray:
     """utils/score_booster.py:17-20 (mode "threshold") and :33-36 ("for_pos" / "for_neg"), elementwise in fp32."""
     s = np.asarray(score, np.float32)
