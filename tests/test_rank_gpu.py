@@ -354,3 +354,25 @@ def test_split_scores_do_not_depend_on_tile_or_batch_shape():
     v64, i64 = M.cosine_topk(q[:64], g, 3)
     assert torch.equal(v[:64], v64) and torch.equal(i[:64], i64)
     assert torch.equal(v, torch.gather(S, 1, i))
+
+
+@pytest.mark.parametrize("Q,G,D,k", [(5, 257, 100, 3), (64, 1500, 1000, 3), (65, 129, 16, 1), (129, 4097, 36, 8), (200, 3000, 2560, 2)])
+def test_split_loop_on_ragged_shapes_and_wide_dynamic_range(Q, G, D, k):
+    """The split loop at shapes that end inside a tile / a k-step (D % 16 != 0, partial row and column tiles, 64- and
+    128-row tiles) with rows whose norms span 19 orders of magnitude, all above the eps clamp (the bf16 planes keep fp32's exponent range):
+    scores within 1e-5 of the float64 cosine, top-k identical to the float64 ranking wherever its gaps are clear."""
+    rng = np.random.default_rng(Q * 1000 + D)
+    q = (synth.normal(300 + Q, (Q, D)) * 10.0 ** rng.uniform(-4, 15, (Q, 1))).astype(np.float32)
+    g = (synth.normal(400 + G, (G, D)) * 10.0 ** rng.uniform(-4, 15, (G, 1))).astype(np.float32)
+    want = _f64_cosine(q, g)
+    s = M.cosine_scores(dev(q), dev(g)).cpu().numpy().astype(np.float64)
+    assert np.isfinite(s).all()
+    np.testing.assert_allclose(s, want, rtol=0, atol=SCORE_TOL)
+    assert np.abs(s - want).max() < 1e-6
+    v, i = M.cosine_topk(dev(q), dev(g), k)
+    order = np.argsort(-want, axis=1, kind="stable")[:, : k + 1]
+    srt = np.take_along_axis(want, order, 1)
+    clear = (srt[:, :-1] - srt[:, 1:]).min(1) > 2e-6
+    assert clear.sum() >= Q * 0.9
+    np.testing.assert_array_equal(i.cpu().numpy()[clear], order[clear][:, :k])
+    np.testing.assert_allclose(v.cpu().numpy(), srt[:, :k], rtol=0, atol=SCORE_TOL)
