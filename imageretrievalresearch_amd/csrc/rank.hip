@@ -973,7 +973,7 @@ static RankWs carve(void* ws, i64 Q, i64 G, int D, int k, bool need_ginv, bool n
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
     r.qn = (float*)take((size_t)Q * D * sizeof(float));
     const i64 q_split = need_S ? qb : (Q < 256 * 64 ? Q : 256 * 64);      // queries of one cos_gemm call
-    r.qs = (bf16_t*)take(Q > 4 ? split_queries_bytes(q_split, D) : 0);
+    r.qs = (bf16_t*)take(split_queries_bytes(q_split, D));   // (also for Q <= 4: rows too long for the GEMV's LDS copy take the GEMM)
     r.ginv = (float*)take(need_ginv ? (size_t)G * sizeof(float) : 0);
     if (fused) {
         const size_t ncand = (size_t)qb * cdiv(G, RK_BN) * k;

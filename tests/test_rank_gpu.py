@@ -376,3 +376,15 @@ def test_split_loop_on_ragged_shapes_and_wide_dynamic_range(Q, G, D, k):
     assert clear.sum() >= Q * 0.9
     np.testing.assert_array_equal(i.cpu().numpy()[clear], order[clear][:, :k])
     np.testing.assert_allclose(v.cpu().numpy(), srt[:, :k], rtol=0, atol=SCORE_TOL)
+
+
+def test_few_queries_with_rows_too_long_for_the_gemv():
+    """Q <= 4 normally streams the gallery as a GEMV with the queries in LDS; rows longer than that LDS copy (60 KB) take
+    the GEMM path, whose split planes must then be part of the workspace too."""
+    Q, G, D = 3, 300, 6000
+    q, g = synth.normal(61, (Q, D)), synth.normal(62, (G, D))
+    want = _f64_cosine(q, g)
+    s = M.cosine_scores(dev(q), dev(g)).cpu().numpy()
+    np.testing.assert_allclose(s, want, rtol=0, atol=1e-6)
+    v, i = M.cosine_topk(dev(q), dev(g), 3)
+    np.testing.assert_array_equal(i.cpu().numpy(), np.argsort(-want, axis=1)[:, :3])
