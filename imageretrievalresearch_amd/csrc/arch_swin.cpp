@@ -41,10 +41,11 @@ int build_swin_base(ModelDef& m) {
             m.add(p + ".mlp.fc2.bias", {dim});
 
             Op ln1; ln1.kind = OP_LAYERNORM; ln1.in = SLOT_X0; ln1.out = SLOT_T0; ln1.cin = ln1.cout = ln1.cin_real = ln1.cout_real = dim;
-            ln1.tokens_h = res; ln1.w_name = p + ".norm1.weight"; ln1.bias_name = p + ".norm1.bias";
+            ln1.tokens_h = res; ln1.w_name = p + ".norm1.weight"; ln1.bias_name = p + ".norm1.bias"; ln1.fuse_next = true;
             m.ops.push_back(ln1);
             Op qkv; qkv.kind = OP_GEMM; qkv.in = SLOT_T0; qkv.out = SLOT_T1; qkv.cin = qkv.cin_real = dim;
             qkv.cout = qkv.cout_real = 3 * dim; qkv.tokens_h = res; qkv.w_name = p + ".attn.qkv.weight"; qkv.bias_name = p + ".attn.qkv.bias";
+            qkv.ln_w_name = p + ".norm1.weight"; qkv.ln_b_name = p + ".norm1.bias";
             m.ops.push_back(qkv);
             Op at; at.kind = OP_WINATTN; at.in = SLOT_T1; at.out = SLOT_T2; at.cin = at.cin_real = 3 * dim; at.cout = at.cout_real = dim;
             at.heads = nh; at.window = ws; at.shift = shift; at.tokens_h = res; at.aux_name = p + ".attn.relative_position_bias_table";
@@ -56,6 +57,7 @@ int build_swin_base(ModelDef& m) {
             m.ops.push_back(ln2);
             Op f1; f1.kind = OP_GEMM; f1.in = SLOT_T0; f1.out = SLOT_T1; f1.cin = f1.cin_real = dim; f1.cout = f1.cout_real = 4 * dim;
             f1.act = ACT_GELU; f1.tokens_h = res; f1.w_name = p + ".mlp.fc1.weight"; f1.bias_name = p + ".mlp.fc1.bias";
+            f1.ln_w_name = p + ".norm2.weight"; f1.ln_b_name = p + ".norm2.bias";
             m.ops.push_back(f1);
             Op f2; f2.kind = OP_GEMM; f2.in = SLOT_T1; f2.out = SLOT_X0; f2.res = SLOT_X0; f2.cin = f2.cin_real = 4 * dim;
             f2.cout = f2.cout_real = dim; f2.tokens_h = res; f2.w_name = p + ".mlp.fc2.weight"; f2.bias_name = p + ".mlp.fc2.bias";

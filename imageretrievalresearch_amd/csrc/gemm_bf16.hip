@@ -425,6 +425,28 @@ __global__ __launch_bounds__(256, BKT == 32 ? 3 : 1) void k_gemm_big(const GemmA
         __syncthreads();   // next tile has landed (vmcnt(0)) and everyone is done reading this one
     }
 
+    // LayerNorm of the A rows, folded in (swin norm1 -> qkv, norm2 -> fc1): the weights carry gamma, the bias carries W beta, and
+    // LN(x) W^T = rstd (x W'^T - mean colsum(W')) - two FMAs per output here instead of a pass that writes and re-reads LN(x)
+    if (!GATED && g.ln_stats) {
+        float mean[MI], rstd[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = min(m0 + row_base + mi * 16 + fr, g.M - 1);
+            const mi355_f32x2 st = *reinterpret_cast<const mi355_f32x2*>(g.ln_stats + (size_t)m * 2);
+            mean[mi] = st.x; rstd[mi] = st.y;
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + col_base + ni * 16 + fq * 4;
+            f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+            if (n < Npad) cs = *reinterpret_cast<const f32x4*>(g.ln_colsum + n);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                acc[ni][mi].x = rstd[mi] * (acc[ni][mi].x - mean[mi] * cs.x); acc[ni][mi].y = rstd[mi] * (acc[ni][mi].y - mean[mi] * cs.y);
+                acc[ni][mi].z = rstd[mi] * (acc[ni][mi].z - mean[mi] * cs.z); acc[ni][mi].w = rstd[mi] * (acc[ni][mi].w - mean[mi] * cs.w);
+            }
+        }
+    }
     // epilogue (same contract as k_gemm_bf16): lane holds n = .. + fq*4 + r, m = .. + fr
     MI355_ACT_DISPATCH(g.act, {
 _Pragma("unroll")
@@ -1060,7 +1082,7 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t st) {
                   a.N, a.ldo);
     MI355_REQUIRE(!a.res || a.ldr % 4 == 0, "gemm: residual stride %d must be a multiple of 4", a.ldr);
     static const int use_splitk = getenv("MI355_GEMM_SPLITK") ? atoi(getenv("MI355_GEMM_SPLITK")) : 1;
-    if (use_splitk && a.splitk_ws && !a.out_f32 && a.ldo % 4 == 0) {
+    if (use_splitk && a.splitk_ws && !a.out_f32 && a.ldo % 4 == 0 && !a.ln_stats) {   // (the split-K reduction has no LayerNorm epilogue)
         const int nch = gemm_splitk_chunks(a.M, a.rows_per_img > 0 ? a.rows_per_img : a.M, a.N, a.K);
         if (nch >= 2 && gemm_splitk_bytes(a.M, a.N, a.K) <= a.splitk_ws_bytes && (!a.gate || a.gate_ld % 4 == 0))
             return launch_splitk(a, nch, st);
@@ -1070,6 +1092,11 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t st) {
     // makes the block LDS-bound); they stay instantiated for tiny-M problems (classifier, M = batch).
     // K-deep shapes: DMA-staged 128x128x64 kernel (2.6x the register-staged kernel on the 7x7 projections:
     // 21 us vs 55 us at M=12544, N=232, K=1392); gated / ReLU6'd A operands use the fragment-gating variant
+    if (a.ln_stats) {   // only k_gemm_big<false, ..> has the LayerNorm epilogue: the executor must not ask for it elsewhere
+        const bool ktail_ = (a.K % 64 != 0) || (a.ldw % 64 != 0);
+        MI355_REQUIRE(a.zeros && a.K >= 128 && a.N >= 96 && a.M >= 1024 && ((uintptr_t)a.A % 16 == 0) && a.lda % 8 == 0 && !a.gate &&
+                      !a.a_relu6 && !ktail_, "gemm: LayerNorm folding needs the DMA-tiled kernel (M=%d N=%d K=%d)", a.M, a.N, a.K);
+    }
     if (a.zeros && a.K >= 128 && a.N >= 64 && a.M >= 1024 && ((uintptr_t)a.A % 16 == 0) && a.lda % 8 == 0 &&
         (!a.gate || a.gate_ld >= a.K)) {
         // 128-wide column tiles for the gated variant: one tile needs N >= 72, several need < ~37 % padding

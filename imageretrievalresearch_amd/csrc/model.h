@@ -34,7 +34,7 @@ enum OpKind {
 // rotating buffers is enough; each slot is sized to the largest tensor any op writes into it.
 enum Slot {
     SLOT_NONE = -1, SLOT_X0 = 0, SLOT_X1, SLOT_E, SLOT_D, SLOT_POOLPART, SLOT_GATE, SLOT_HEAD, SLOT_POOLED,
-    SLOT_POOLED_BF16, SLOT_T0, SLOT_T1, SLOT_T2, SLOT_T3, SLOT_SPLITK, SLOT_COUNT
+    SLOT_POOLED_BF16, SLOT_T0, SLOT_T1, SLOT_T2, SLOT_T3, SLOT_SPLITK, SLOT_LNSTATS, SLOT_COUNT
 };
 
 struct Op {
@@ -53,6 +53,12 @@ struct Op {
     // swin
     int heads = 0, window = 0, shift = 0, tokens_h = 0;
     float ln_eps = 1e-5f;
+    // LayerNorm folded into the consumer GEMM (swin norm1 -> qkv, norm2 -> fc1).  LN op: fuse_next = the next op is that GEMM.
+    // GEMM op: ln_w_name / ln_b_name = the LayerNorm's gamma / beta; pack() then also stores W' = bf16(W * gamma) (w_ln_off),
+    // b' = b + W beta (b_ln_off) and the column sums of W' (cs_off), so that  LN(x) W^T + b = rstd (x W'^T - mean cs) + b'.
+    bool fuse_next = false;
+    std::string ln_w_name, ln_b_name;
+    size_t w_ln_off = 0, b_ln_off = 0, cs_off = 0;
     // packed-weight offsets (bytes into the device blob), filled by pack()
     size_t w_off = 0, b_off = 0, w2_off = 0, b2_off = 0, aux_off = 0;
     size_t w3_off = 0, w4_off = 0;  // SE: bf16 copies of the two FC matrices (whole-block kernel, mbconv_block.hip)

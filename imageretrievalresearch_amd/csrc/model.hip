@@ -32,6 +32,33 @@ int pack_gemm(Packer& pk, Op& op) {
         for (int k = 0; k < K; ++k) W[(size_t)n * Kp + k] = f2bf_host(w->data[(size_t)n * K + k] * scale[n]);
         Bv[n] = shift[n];
     }
+    if (!op.ln_w_name.empty()) {   // LayerNorm folded into this GEMM (see Op::fuse_next)
+        const TensorSpec* g = pk.get(op.ln_w_name);
+        const TensorSpec* be = pk.get(op.ln_b_name);
+        if (!g || !be) return ERR_STATE;
+        MI355_REQUIRE(g->numel() == K && be->numel() == K, "pack: %s / %s must have %d elements", op.ln_w_name.c_str(),
+                      op.ln_b_name.c_str(), K);
+        op.w_ln_off = pk.alloc((size_t)Np * Kp * 2);
+        op.b_ln_off = pk.alloc((size_t)Np * 4);
+        op.cs_off = pk.alloc((size_t)Np * 4);
+        uint16_t* W2 = (uint16_t*)(pk.blob.data() + op.w_ln_off);
+        float* B2 = (float*)(pk.blob.data() + op.b_ln_off);
+        float* CS = (float*)(pk.blob.data() + op.cs_off);
+        const float* Bv1 = (const float*)(pk.blob.data() + op.b_off);     // (alloc may have moved the blob)
+        for (int n = 0; n < N; ++n) {
+            double cs = 0.0, bb = 0.0;
+            for (int k = 0; k < K; ++k) {
+                const float wv = w->data[(size_t)n * K + k] * scale[n];
+                const uint16_t h = f2bf_host(wv * g->data[k]);
+                W2[(size_t)n * Kp + k] = h;
+                uint32_t u = (uint32_t)h << 16; float hf; memcpy(&hf, &u, 4);
+                cs += hf;
+                bb += (double)wv * be->data[k];
+            }
+            CS[n] = (float)cs;
+            B2[n] = Bv1[n] + (float)bb;
+        }
+    }
     return OK;
 }
 
@@ -171,6 +198,7 @@ static size_t plan_slots(mi355_model* m, int nb, int H, int W) {
                     S[op.out].h = th; S[op.out].w = th; S[op.out].c = op.cout;
                     need(op.out, (size_t)nb * th * th * op.cout * 2);
                 }
+                if (op.kind == OP_LAYERNORM && op.fuse_next) need(SLOT_LNSTATS, (size_t)nb * th * th * 8);
                 break;
             }
         }
@@ -266,6 +294,15 @@ static int exec_op(ExecCtx& cx, const Op& op) {
             a.M = cx.nb * hw; a.N = op.cout; a.K = op.cin;
             a.act = op.act; a.a_relu6 = op.a_relu6;
             a.zeros = (const bf16_t*)cx.w(0);
+            if (cx.ln_pending_in != SLOT_NONE) {      // the preceding LayerNorm only left (mean, rstd) per row: fold it in here
+                MI355_REQUIRE(op.w_ln_off && op.in != SLOT_NONE, "exec: GEMM after a fused LayerNorm has no folded weights");
+                a.A = (const bf16_t*)cx.slot_ptr(cx.ln_pending_in);
+                a.W = (const bf16_t*)cx.w(op.w_ln_off);
+                a.bias = (const float*)cx.w(op.b_ln_off);
+                a.ln_stats = (const float*)cx.slot_ptr(SLOT_LNSTATS);
+                a.ln_colsum = (const float*)cx.w(op.cs_off);
+                cx.ln_pending_in = SLOT_NONE;
+            }
             if (m->slots[SLOT_SPLITK].bytes) {
                 a.splitk_ws = (float*)cx.slot_ptr(SLOT_SPLITK);
                 a.splitk_ws_bytes = m->slots[SLOT_SPLITK].bytes;
@@ -786,6 +823,7 @@ int mi355_model_set_option(mi355_model_t m, const char* key, int64_t value) {
     else if (k == "sweep_variant") m->sweep_variant = (int)value;
     else if (k == "sweep_skip") m->sweep_skip = (int)value;
     else if (k == "fuse_debug") m->fuse_debug = (int)value;
+    else if (k == "fuse_ln") m->fuse_ln = (int)value;
     else if (k == "fuse_block") m->fuse_block = (int)value;
     else if (k == "fuse_block_min_batch") m->fuse_block_min_batch = (int)value;
     else if (k == "block_stamps") m->block_stamps = value != 0;

@@ -70,6 +70,7 @@ struct mi355_model {
     bool block_stamps = false;  // option "block_stamps": record per-phase cycle counts of the block kernel
     long long* stamp_buf = nullptr; size_t stamp_bytes = 0; int stamp_B = 0;
     int fuse_debug = 0;
+    int fuse_ln = 1;            // swin: LayerNorm as a statistics pass + the consumer GEMM's epilogue (option "fuse_ln"; 0 = separate LayerNorm kernel)
     int pool_nblk = 0;          // squeeze partials per image produced by the last depthwise stage
     bool taps = false;
     std::map<std::string, TapBuf> tapbufs;
@@ -96,6 +97,7 @@ struct ExecCtx {
     int img_h = 0, img_w = 0, fill = 255;
     float mean[3] = {0.f, 0.f, 0.f}, stdv[3] = {1.f, 1.f, 1.f};
     const float* conv_w = nullptr;          // optional conv_input weights (device)
+    int ln_pending_in = SLOT_NONE;          // a fused LayerNorm left its row statistics in SLOT_LNSTATS: the next GEMM reads this slot instead
     char* base() const { return (char*)m->arena + (size_t)lane * m->lane_bytes; }
     void* slot_ptr(int s) const { return s == SLOT_NONE ? nullptr : base() + m->slots[s].off; }
     const char* w(size_t off) const { return (const char*)m->dev_blob + off; }

@@ -23,6 +23,9 @@ struct GemmArgs {
     const bf16_t* zeros;   // >= 64 bytes of device zeros (source of out-of-range DMA chunks); null disables the DMA path
     float* splitk_ws;      // optional fp32 scratch for the split-K path (gemm_splitk_bytes); null disables it
     size_t splitk_ws_bytes;
+    // LayerNorm of the A rows folded into the epilogue (k_gemm_big only): out = rstd[m] * (acc - mean[m] * ln_colsum[n]) + bias[n]
+    const float* ln_stats;   // [M][2] = (mean, rstd) of every A row, or null
+    const float* ln_colsum;  // [ceil16(N)] column sums of the (gamma-folded) weights
 };
 int launch_gemm_bf16(const GemmArgs& a, hipStream_t st);
 // Split-K for the tiny-M late projections (7x7 / 14x14 maps at small batch: a handful of output tiles, each with a serial

@@ -120,7 +120,9 @@ __global__ __launch_bounds__(256) void k_patch_embed(const float* __restrict__ x
 // C = LPR * VPL * 8.  MERGE: the input row is the 2x2 patch-merge concat [x(2y,2x), x(2y+1,2x), x(2y,2x+1),
 // x(2y+1,2x+1)] of a [B][2*gh][2*gw][C/4] tensor (timm PatchMerging order), gathered on load.
 // =====================================================================================
-template <int LPR, int VPL, bool MERGE>
+// STATS: write only (mean, rstd) of every row (float2 stats[rows], through `out`): the consumer GEMM applies the
+// normalisation in its epilogue (Op::fuse_next), so the normalised tensor is never written or re-read.
+template <int LPR, int VPL, bool MERGE, bool STATS = false>
 __global__ __launch_bounds__(256) void k_layernorm(const bf16_t* __restrict__ in, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, bf16_t* __restrict__ out, long rows,
                                                    int gh, int gw, float eps) {
@@ -162,6 +164,10 @@ __global__ __launch_bounds__(256) void k_layernorm(const bf16_t* __restrict__ in
         for (int j = 0; j < 8; ++j) { v[i][j] -= mean; q += v[i][j] * v[i][j]; }
     const float rstd = rsqrtf(group_sum<LPR>(q) * (1.0f / C) + eps);
     if (!live) return;
+    if (STATS) {
+        if (sub == 0) { float* st = reinterpret_cast<float*>(out) + row * 2; st[0] = mean; st[1] = rstd; }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int c0 = (sub + i * LPR) * 8;
@@ -174,11 +180,11 @@ __global__ __launch_bounds__(256) void k_layernorm(const bf16_t* __restrict__ in
     }
 }
 
-template <bool MERGE>
+template <bool MERGE, bool STATS = false>
 static int launch_ln(const bf16_t* in, const float* g, const float* b, bf16_t* out, long rows, int C, int gh, int gw,
                      float eps, hipStream_t st) {
 #define LN_CASE(LPR, VPL)                                                                                  \
-    hipLaunchKernelGGL((k_layernorm<LPR, VPL, MERGE>), dim3((unsigned)cdiv(rows, 256 / LPR)), dim3(256), 0, st, in, g, b, \
+    hipLaunchKernelGGL((k_layernorm<LPR, VPL, MERGE, STATS>), dim3((unsigned)cdiv(rows, 256 / LPR)), dim3(256), 0, st, in, g, b, \
                        out, rows, gh, gw, eps)
     switch (C) {
         case 128: LN_CASE(16, 1); break;
@@ -458,6 +464,13 @@ int swin_exec(const ModelDef& def, const Op& op, ExecCtx& cx) {
         }
         case OP_LAYERNORM: {
             const long rows = (long)cx.nb * op.tokens_h * op.tokens_h;
+            // Folded into the next GEMM (norm1 -> qkv, norm2 -> fc1) when that GEMM takes the DMA-tiled kernel, whose epilogue
+            // knows how (M >= 1024 rows; smaller problems keep the separate kernel and the unfolded weights)
+            if (op.fuse_next && cx.m->fuse_ln && rows >= 1024 && cx.m->slots[SLOT_LNSTATS].bytes >= (size_t)rows * 8) {
+                cx.ln_pending_in = op.in;
+                return launch_ln<false, true>((const bf16_t*)cx.slot_ptr(op.in), nullptr, nullptr, (bf16_t*)cx.slot_ptr(SLOT_LNSTATS),
+                                              rows, op.cout, 0, 0, op.ln_eps, cx.st);
+            }
             return launch_ln<false>((const bf16_t*)cx.slot_ptr(op.in), (const float*)cx.w(op.w_off), (const float*)cx.w(op.b_off),
                                     (bf16_t*)cx.slot_ptr(op.out), rows, op.cout, 0, 0, op.ln_eps, cx.st);
         }

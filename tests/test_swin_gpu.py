@@ -21,13 +21,18 @@ def setup():
     return sd, model
 
 
-def test_swin_blocks_match_bf16_sim_oracle(setup):
+@pytest.mark.parametrize("fuse_ln", [1, 0])
+def test_swin_blocks_match_bf16_sim_oracle(setup, fuse_ln):
+    """fuse_ln = 1 (default): norm1 / norm2 of the 56x56 and 28x28 stages run as a statistics pass + the qkv / fc1 GEMM's
+    epilogue (the 14x14 / 7x7 stages have fewer than 1024 rows at this batch and keep the separate kernel); 0: all separate."""
     sd, model = setup
     x = torch.from_numpy(images(51, 2))
     taps = {}
     want = swin.forward_features(sd, x, sim_bf16=True, taps=taps)
+    model.set_option("fuse_ln", fuse_ln)
     model.enable_taps(True)
     got = model.forward_features(x.to(DEV))
+    model.set_option("fuse_ln", 1)
     worst = ("", 0.0)
     for name, ref in taps.items():
         t = model.read_tap(name).cpu()                      # (B, C, h, w) view of the token tensor
@@ -112,3 +117,22 @@ def test_short_k_gemm_instantiation_matches_the_default_one(N, act):
     ref = {0: lambda t: t, 1: torch.nn.functional.silu, 4: torch.nn.functional.gelu}[act](ref)
     err = (big.float() - ref).abs().max().item()
     assert err < 2.0 ** -7 * max(1.0, ref.abs().max().item()), err      # one bf16 rounding of the output
+
+
+def test_layernorm_folded_into_the_gemm_agrees_with_the_separate_kernel():
+    """B = 24: every stage has >= 1024 token rows, so all 48 norm1 / norm2 LayerNorms run as a (mean, rstd) pass plus the
+    consumer GEMM's epilogue  rstd (x W'^T - mean colsum(W')) + b'  with gamma folded into W' and beta into b'.  Against the
+    separate LayerNorm kernel the embedding may differ by bf16 rounding only (the normalised tensor is no longer rounded to
+    bf16 before the product; the folded weights are rounded once more); both are deterministic."""
+    from imageretrievalresearch_amd import synth
+    model = M.create_model("swin_base_patch4_window7_224", num_classes=0, seed=6).to(DEV).eval()
+    B = 24
+    x = M.synth_fill(B * 3 * 224 * 224, 83, synth.UNIFORM, DEV).view(B, 3, 224, 224)
+    model.set_option("fuse_ln", 1)
+    a = model(x).clone()
+    assert torch.equal(a, model(x))
+    model.set_option("fuse_ln", 0)
+    b = model(x).clone()
+    model.set_option("fuse_ln", 1)
+    assert torch.isfinite(a).all() and rel(a.cpu(), b.cpu()) < 1e-2
+    assert not torch.equal(a, b)          # the two paths really are different code
