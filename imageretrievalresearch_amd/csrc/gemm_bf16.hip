@@ -1097,6 +1097,14 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t st) {
         MI355_REQUIRE(a.zeros && a.K >= 128 && a.N >= 96 && a.M >= 1024 && ((uintptr_t)a.A % 16 == 0) && a.lda % 8 == 0 && !a.gate &&
                       !a.a_relu6 && !ktail_, "gemm: LayerNorm folding needs the DMA-tiled kernel (M=%d N=%d K=%d)", a.M, a.N, a.K);
     }
+    // Short K (64 .. 128, any tail), outputs at least twice as wide as the inputs, many rows (RexNet's 77->462 @56x56, 100->600 and
+    // 122->732 @28x28; Swin's K = 128 linears take the same instantiation below): the three-workgroup form of the DMA kernel
+    static const int short_min_k = getenv("MI355_GEMM_SHORT_MIN_K") ? atoi(getenv("MI355_GEMM_SHORT_MIN_K")) : 64;
+    if (a.zeros && a.K >= short_min_k && a.K < 128 && a.N >= 2 * a.K && a.N >= 96 && a.M >= 32768 && ((uintptr_t)a.A % 16 == 0) &&
+        a.lda % 8 == 0 && !a.gate && !a.a_relu6 && !a.ln_stats) {
+        const bool ktail32 = (a.K % 32 != 0) || (a.ldw % 32 != 0);
+        return ktail32 ? launch_big<false, true, 32>(a, st) : launch_big<false, false, 32>(a, st);
+    }
     if (a.zeros && a.K >= 128 && a.N >= 64 && a.M >= 1024 && ((uintptr_t)a.A % 16 == 0) && a.lda % 8 == 0 &&
         (!a.gate || a.gate_ld >= a.K)) {
         // 128-wide column tiles for the gated variant: one tile needs N >= 72, several need < ~37 % padding
