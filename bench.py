@@ -30,6 +30,8 @@ sys.path.insert(0, ROOT)
 import imageretrievalresearch_amd as M  # noqa: E402
 from imageretrievalresearch_amd import synth  # noqa: E402
 
+PMC_EMBED = "r03_pmc_traffic_effnet_b256.json"     # committed PMC summaries (tools/refresh_profiles.sh), used for `traffic`
+PMC_RANK = "r03_pmc_rank_kernels.json"
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 D = 1536
 GALLERY_ROWS = 100_000
@@ -46,8 +48,9 @@ def parse():
     ap.add_argument("--gallery", type=int, default=GALLERY_ROWS)
     ap.add_argument("--microbatch", type=int, default=int(os.environ.get("MI355_MICROBATCH", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=2, choices=(1, 2),
-                    help="2: embed on one HIP stream, rank on a second (rank of batch i beside embed of batch i+1); 1: one stream")
+    ap.add_argument("--streams", type=int, default=1, choices=(1, 2),
+                    help="1 (default): embed then rank on one HIP stream; 2: rank of batch i on a second stream beside the embed "
+                         "of batch i+1 (measured: hides <= 1 %% - the embed kernels fill the CUs - and adds launch-time variance)")
     ap.add_argument("--model", default="efficientnet_b3a")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
@@ -130,8 +133,11 @@ def main():
     gal = M.ShardedGallery(shard)
     del shard
 
-    # Embed on one HIP stream, rank on a second one: the rank of batch i (exact-f32 MFMA, compute-bound) overlaps the
-    # embed of batch i+1 (bandwidth/latency-bound).  Every step's embed AND rank complete inside the timed region.
+    # One HIP stream by default: a step is embed THEN rank (split-bf16 MFMA loop).  With --streams 2 the rank of batch i is
+    # enqueued on a second stream beside the embed of batch i+1; round 2 measured that this hides <= 1 % (the embed kernels
+    # occupy the whole register file / LDS of every CU, so rank workgroups only run in the gaps) and that it makes kernel
+    # durations erratic (k_dw3_lds 124-472 us), so it is no longer the default.  Every step's embed AND rank complete inside
+    # the timed region either way.
     s_embed, s_rank = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
 
     def step():
@@ -242,7 +248,7 @@ def main():
         # HBM bytes of that launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs, gfx950
         # x2 read correction) - cannot be collected from inside this process; null when the summary is from other code
         traffic, traffic_source = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic_effnet_b256.json")
+        pmc_path = os.path.join(ROOT, "profiles", PMC_EMBED)
         if a.model == "efficientnet_b3a" and a.batch == 256 and os.path.exists(pmc_path):
             with open(pmc_path) as f:
                 pmc = json.load(f)
@@ -250,13 +256,26 @@ def main():
                 ent = pmc.get("per_op", {}).get(top[0])
                 if ent:
                     traffic = ent["hbm_bytes_per_launch"]
-                    traffic_source = "profiles/r02_pmc_traffic_effnet_b256.json (rocprofv3 --pmc, separate passes, same kernel sources)"
+                    traffic_source = f"profiles/{PMC_EMBED} (rocprofv3 --pmc, separate passes, same kernel sources)"
+        # the rank GEMM's HBM-side read bytes per launch, same provenance rule (tools/refresh_profiles.sh: bench_rank.py with
+        # CASES=256x100000 under --pmc FETCH_SIZE).  RAW counter x 1024: the gallery arrives as 64-byte-per-row LDS-DMA pieces,
+        # for which the gfx950 "x2 for wide coalesced reads" correction does not apply (x2 would exceed the HBM peak)
+        rank_traffic, rank_traffic_source = None, None
+        rk_path = os.path.join(ROOT, "profiles", PMC_RANK)
+        if a.batch == 256 and (hi - lo) == 100_000 and os.path.exists(rk_path):
+            with open(rk_path) as f:
+                rk = json.load(f)
+            if rk.get("csrc_sha16") == csrc_sha16():
+                ent = rk.get("kernels", {}).get("void mi355::k_cos_gemm_split<2, 4>")
+                if ent and "FETCH_SIZE" in ent:
+                    rank_traffic = ent["FETCH_SIZE"] * 1024.0
+                    rank_traffic_source = f"profiles/{PMC_RANK} (rocprofv3 --pmc FETCH_SIZE, raw counter x 1024 per launch of the main tile launch)"
         roofline = {"bound": "hbm", "kernel": f"{kname} @ {top[0]}", "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                     "avg_launch_ms": top[2], "launches_per_forward": dom["n"], "ms_per_forward": dom["ms"],
                     "ops_in_launch": top[5], "algorithmic_bytes_per_launch": top[3],
                     "bytes_model": "SURVEY 8d layer-granular bytes of every op the launch executes (fused intermediates included)",
-                    "note": "fused kernels are VALU / latency-bound, not HBM-bound (PMC per launch: profiles/r02_pmc_traffic_effnet_b256.json; "
+                    "note": f"fused kernels are VALU / latency-bound, not HBM-bound (PMC per launch: profiles/{PMC_EMBED}; "
                             "whole-forward fraction: embed_roofline)",
                     "family_ms_per_forward": {k: v["ms"] / nprof for k, v in prof.items() if v["launches"]},
                     "family_GBps": {k: tr["bytes_by_kind"][k] / (v["ms"] / nprof * 1e-3) / 1e9
@@ -298,7 +317,9 @@ def main():
                 "bound": "mfma-f32" if exact else "mfma-bf16 (fp32 operands as 3 bf16 planes, 6 products, fp32 accumulate)",
                 "tflops": tf, "executed_tflops": tf if exact else 6.0 * tf,
                 "peak_tflops": 157.3 if exact else 2500.0, "frac": tf / 157.3 if exact else 6.0 * tf / 2500.0,
-                "vs_fp32_mfma_peak": tf / 157.3})(2.0 * a.batch * (hi - lo) * D / t_rank / 1e12,
+                "vs_fp32_mfma_peak": tf / 157.3,
+                "algorithmic_bytes": 4.0 * (hi - lo) * D + 6.0 * a.batch * D, "traffic": rank_traffic,
+                "traffic_source": rank_traffic_source})(2.0 * a.batch * (hi - lo) * D / t_rank / 1e12,
                                                   os.environ.get("MI355_RANK_EXACT_F32", "0") not in ("", "0")),
             "roofline": roofline,
         }

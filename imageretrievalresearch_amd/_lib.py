@@ -31,6 +31,9 @@ PROTOTYPES = {
                                       C.c_size_t, vp]),
     "mi355_topk_rows": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int64, vp, vp, vp, C.c_size_t, vp]),
     "mi355_merge_topk": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp, vp, vp, C.c_size_t, vp]),
+    "mi355_pack_candidates": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp, vp]),
+    "mi355_merge_packed_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
+    "mi355_merge_packed_topk": (C.c_int, [vp, vp, C.c_int, C.c_int64, C.c_int, vp, vp, vp, C.c_size_t, vp]),
     "mi355_pair_cosine": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_float, vp, vp]),
     "mi355_contrastive_loss": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_int, vp, vp, vp]),
     "mi355_cosine_embedding_loss": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_int, vp, vp]),
@@ -88,8 +91,8 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)  # AttributeError here = header/library mismatch: fail loudly
             fn.restype = res
             fn.argtypes = args
-        if L.mi355_abi_version() != 2:
-            raise ImportError(f"ABI version mismatch: library {L.mi355_abi_version()} != binding 2")
+        if L.mi355_abi_version() != 3:
+            raise ImportError(f"ABI version mismatch: library {L.mi355_abi_version()} != binding 3")
         _lib = L
     return _lib
 

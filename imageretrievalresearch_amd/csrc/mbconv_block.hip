@@ -86,10 +86,18 @@ template <int KS> struct MbTaps {
 //          fragments are requested one phase ahead and the k-loop issues no loads (hipcc cannot count waits for
 //          loop-carried loads: every in-loop refill became a vmcnt(0), i.e. an exposed L2 round trip per k-step)
 //   A_IT   16-byte pieces of a projection A chunk (128 deep, 256 for the 7x7 class) staged per thread
-template <int KS, int S, int WI, int NWM, int CW, int MW, int NTW, int MWP, int WRING, int A_IT>
+//   MH   passes over the pixel tiles in the expand GEMM (NWM == 1 only): pass h covers tiles h * MW .. h * MW + MW - 1 with the
+//        same weight fragments, which halves the accumulator / fragment registers of the 14x14 class
+// NWM == 1 makes the slab loop BARRIER-FREE: a wave then expands all pixels of its own CW channel tiles and the depthwise
+// phase of the same wave consumes exactly those channels of the E image (LDS operations of one wave execute in order), so
+// the eight waves drift apart and one wave's MFMA phase overlaps its SIMD partner's SiLU / LDS phase.  With NWM == 2 two
+// waves shared a channel tile and every slab needed two workgroup barriers (12 - 20 % of the block at 2 waves per SIMD).
+template <int KS, int S, int WI, int NWM, int CW, int MW, int NTW, int MWP, int WRING, int A_IT, int MH = 1>
 __global__ __launch_bounds__(MB_THREADS) void k_mbconv_block(const BlockArgs a) {
     using TP = MbTaps<KS>;
     constexpr int NWN = MB_WAVES / NWM;
+    constexpr bool INDEP = NWM == 1;                  // a wave consumes only the E channels it produced
+    static_assert(MH == 1 || NWM == 1, "several passes over the pixel tiles need a wave that owns whole channel tiles");
     constexpr int MC = NWN * CW * 16;                 // expanded channels per slab
     constexpr int CTW = MC / 16 / MB_WAVES;           // 16-channel tiles per wave in phase 2 (1 or 2)
     constexpr int PAD = KS / 2;
@@ -227,7 +235,8 @@ __global__ __launch_bounds__(MB_THREADS) void k_mbconv_block(const BlockArgs a) 
         tick(1);
 
         // ---- phase 1: E slab = act(X W^T + b) -> Es.  D = W x X^T: a lane holds 4 consecutive channels of one pixel.
-        {
+#pragma unroll
+        for (int h = 0; h < MH; ++h) {
             f32x4 acc[CW][MW];
 #pragma unroll
             for (int j = 0; j < CW; ++j) {
@@ -241,7 +250,7 @@ __global__ __launch_bounds__(MB_THREADS) void k_mbconv_block(const BlockArgs a) 
             // ~130-cycle LDS latency, and read-wait-MFMA per tile cost 3x the MFMA time
             int arow[MW];
 #pragma unroll
-            for (int i = 0; i < MW; ++i) arow[i] = (min(mq + NWM * i, MT - 1) * 16 + fr) * XLD + fk;
+            for (int i = 0; i < MW; ++i) arow[i] = (min(mq + NWM * (h * MW + i), MT - 1) * 16 + fr) * XLD + fk;
             bf16x8 af[2][MW];
 #pragma unroll
             for (int i = 0; i < MW; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(&Xs[arow[i]]);
@@ -259,9 +268,11 @@ __global__ __launch_bounds__(MB_THREADS) void k_mbconv_block(const BlockArgs a) 
                             acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wq[ks][j]), af[ks & 1][i], acc[j][i], 0, 0, 0);
                 }
             }
-            tick(2);
-            if (ci + 1 < nslabs) w_prefetch_slab(slab_of(ci + 1) * MC);
-            tick(3);
+            if (h == MH - 1) {
+                tick(2);
+                if (ci + 1 < nslabs) w_prefetch_slab(slab_of(ci + 1) * MC);
+                tick(3);
+            }
             MI355_ACT_DISPATCH(a.act_e, {
 _Pragma("unroll")
                 for (int j = 0; j < CW; ++j)
@@ -273,8 +284,9 @@ _Pragma("unroll")
             })
 #pragma unroll
             for (int i = 0; i < MW; ++i) {
-                const int p = (mq + NWM * i) * 16 + fr;      // this lane's pixel in tile i
-                if (mq + NWM * i < MT && p < P) {
+                const int mt = mq + NWM * (h * MW + i);
+                const int p = mt * 16 + fr;                  // this lane's pixel in tile i
+                if (mt < MT && p < P) {
                     const int y = p / WI;
                     const int eoff = (y + PAD) * EW + (p - y * WI) + PAD;
 #pragma unroll
@@ -289,7 +301,8 @@ _Pragma("unroll")
             }
         }
         tick(4);
-        mb_lds_barrier();
+        if (!INDEP || (a.variant & 2)) mb_lds_barrier();      // (bit 1 of the tuning option: barriers kept, for A/B timing)
+        else asm volatile("" ::: "memory");
         tick(5);
 
         // ---- phase 2: depthwise on the (otherwise idle) matrix pipe.  The VALU is the bottleneck of this kernel (two
@@ -389,7 +402,8 @@ _Pragma("unroll")
             }
         }
         tick(6);
-        mb_lds_barrier();   // Es is rewritten by the next slab
+        if (!INDEP || (a.variant & 2)) mb_lds_barrier();      // Es is rewritten by the next slab
+        else asm volatile("" ::: "memory");
         tick(7);
     }
     __syncthreads();      // full fence: the depthwise output (global) is re-read by other waves in the projection
@@ -687,10 +701,12 @@ _Pragma("unroll")
 }
 
 // ------------------------------------------------------------------------------------------ host side
-struct MbGeom { int wi, nwm, cw, mw, ntw, mwp, mc, wring, a_it; };
+struct MbGeom { int wi, nwm, cw, mw, ntw, mwp, mc, wring, a_it, mh; };
 static bool mb_geom(int H, int W, MbGeom* g) {
-    if (W == 7 && H * W <= 64) { *g = {7, 1, 2, 4, 3, 4, 256, 12, 4}; return true; }
-    if (W == 14 && H * W <= 208) { *g = {14, 2, 2, 7, 3, 7, 128, 5, 7}; return true; }
+    if (W == 7 && H * W <= 64) { *g = {7, 1, 2, 4, 3, 4, 256, 12, 4, 1}; return true; }
+    // (both 14x14 geometries - one wave per channel tile in two pixel passes, or two waves per pair of channel tiles - have the
+    //  same slab width, LDS footprint and limits)
+    if (W == 14 && H * W <= 208) { *g = {14, 1, 1, 7, 3, 7, 128, 5, 7, 2}; return true; }
     return false;
 }
 
@@ -742,7 +758,7 @@ bool mbconv_block_supported(int H, int W, int Cin, int mid, int Cout, int k, int
     if (msplit > MTp) msplit = MTp;
     if ((MTp + msplit - 1) / msplit > g.mwp) return false;
     if (Pout * (g.wi == 7 ? 32 : 16) > g.a_it * MB_THREADS) return false;   // staged pieces per thread per K chunk
-    if ((H * W + 15) / 16 > g.nwm * g.mw) return false;
+    if ((H * W + 15) / 16 > g.nwm * g.mw * g.mh) return false;
     if (a.Kp / 32 > g.wring) return false;
     // register budget (hipcc spills, and a spill reload waits for every prefetch in flight): the 7x7 class with a 5x5
     // depthwise holds at most 8 k-steps of weights
@@ -750,7 +766,7 @@ bool mbconv_block_supported(int H, int W, int Cin, int mid, int Cout, int k, int
     return mb_pick_xld(a, k, g) != 0;
 }
 
-template <int KS, int S, int WI, int NWM, int CW, int MW, int NTW, int MWP, int WRING, int A_IT>
+template <int KS, int S, int WI, int NWM, int CW, int MW, int NTW, int MWP, int WRING, int A_IT, int MH = 1>
 static int launch_mb(BlockArgs a, int B, hipStream_t st) {
     MbGeom g;
     mb_geom(a.H, a.W, &g);
@@ -760,11 +776,11 @@ static int launch_mb(BlockArgs a, int B, hipStream_t st) {
     int dev = 0;
     MI355_CHECK_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !attr_done[dev]) {
-        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_mbconv_block<KS, S, WI, NWM, CW, MW, NTW, MWP, WRING, A_IT>,
+        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_mbconv_block<KS, S, WI, NWM, CW, MW, NTW, MWP, WRING, A_IT, MH>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done[dev] = true;
     }
-    hipLaunchKernelGGL((k_mbconv_block<KS, S, WI, NWM, CW, MW, NTW, MWP, WRING, A_IT>), dim3(B), dim3(MB_THREADS), lds, st, a);
+    hipLaunchKernelGGL((k_mbconv_block<KS, S, WI, NWM, CW, MW, NTW, MWP, WRING, A_IT, MH>), dim3(B), dim3(MB_THREADS), lds, st, a);
     MI355_LAUNCH_CHECK();
     return OK;
 }
@@ -775,8 +791,12 @@ static int launch_mb_ks(const BlockArgs& a, int B, hipStream_t st) {
         if (a.Kp <= 256) return launch_mb<KS, S, 7, 1, 2, 4, 3, 4, 8, 4>(a, B, st);
         return launch_mb<KS, S, 7, 1, 2, 4, 3, 4, 12, 4>(a, B, st);
     }
-    if (a.Kp <= 96) return launch_mb<KS, S, 14, 2, 2, 7, 3, 7, 3, 7>(a, B, st);
-    return launch_mb<KS, S, 14, 2, 2, 7, 3, 7, 5, 7>(a, B, st);
+    if (a.variant & 1) {
+        if (a.Kp <= 96) return launch_mb<KS, S, 14, 2, 2, 7, 3, 7, 3, 7>(a, B, st);
+        return launch_mb<KS, S, 14, 2, 2, 7, 3, 7, 5, 7>(a, B, st);
+    }
+    if (a.Kp <= 96) return launch_mb<KS, S, 14, 1, 1, 7, 3, 7, 3, 7, 2>(a, B, st);
+    return launch_mb<KS, S, 14, 1, 1, 7, 3, 7, 5, 7, 2>(a, B, st);
 }
 
 int launch_mbconv_block(const BlockArgs& a, int B, int k, int stride, hipStream_t st) {

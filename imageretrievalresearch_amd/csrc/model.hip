@@ -405,6 +405,7 @@ static int exec_block(ExecCtx& cx, size_t oi) {
     a.act_e = g.act; a.act_d = d.act; a.se_act = s.se_act;
     a.inv_hw = 1.0f / (float)(a.Ho * a.Wo);
     a.norot = m->block_norot;
+    a.variant = m->block_variant;
     a.stamps = nullptr;
     { const int rc = stamp_ptr(cx, oi, &a.stamps); if (rc != OK) return rc; }
     return launch_mbconv_block(a, cx.nb, d.k, d.stride, cx.st);
@@ -828,6 +829,7 @@ int mi355_model_set_option(mi355_model_t m, const char* key, int64_t value) {
     else if (k == "fuse_block_min_batch") m->fuse_block_min_batch = (int)value;
     else if (k == "block_stamps") m->block_stamps = value != 0;
     else if (k == "block_norot") m->block_norot = (int)value;
+    else if (k == "block_variant") m->block_variant = (int)value;
     else if (k == "roctx") roctx_enable(value != 0);   // process-wide: ranges around every executor op and rank phase
     else if (k == "profile") {
         m->profile = value != 0;

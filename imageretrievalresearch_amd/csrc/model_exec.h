@@ -66,6 +66,7 @@ struct mi355_model {
     int fuse_block = 1;         // whole MBConv block in one kernel for the 14x14 / 7x7 stages (option "fuse_block"; 0 = off)
     int fuse_block_min_batch = 192; // ... only for chunks of at least this many images: one workgroup per image needs ~a CU per image
                                     // (measured B=128: 3.16 ms with, 3.01 without; B=256: 4.38 with, 4.7 without; B<=32: +0.4 ms)
+    int block_variant = 0;      // tuning (option "block_variant"): see BlockArgs::variant
     int block_norot = 0;        // diagnosis (option "block_norot"): see BlockArgs::norot
     bool block_stamps = false;  // option "block_stamps": record per-phase cycle counts of the block kernel
     long long* stamp_buf = nullptr; size_t stamp_bytes = 0; int stamp_B = 0;

@@ -87,6 +87,7 @@ struct BlockArgs {
     int H, W, Cin, Kp, mid, Ho, Wo, Cout, Kp2, rd;
     int XLD;                              // LDS row stride of the X image (set by the launcher)
     int norot;                            // diagnosis: bit0 slabs, bit1 SE FC1, bit2 SE FC2, bit3 projection columns NOT rotated by image
+    int variant;                          // tuning (option "block_variant"): bit0 = the round-2 14x14 geometry (two waves share a channel tile, barriers per slab)
     int has_res;
     int act_e, act_d, se_act;
     float inv_hw;

@@ -163,6 +163,24 @@ __device__ __forceinline__ void glds16(const bf16_t* gsrc, bf16_t* lds_dst) {
 // permutation, which only reorders the (exact) fma chain.
 constexpr int RK_BN = 128;
 
+// Launch order of the GEMM tiles (speed only, every result is the same for any order): the grid is one-dimensional and the
+// query blocks of ONE gallery tile get the linear ids L, L + 8, L + 16, ...  The dispatcher deals workgroups round-robin
+// over the 8 XCDs, so those workgroups share an L2 and start in the same round: the gallery tile comes from HBM once and
+// the other query blocks hit it in L2.  (With a (tile, query block) grid, x fastest, all tiles of query block 0 filled the
+// machine before query block 1 started: PMC showed every gallery row fetched from HBM once per query block.)
+__device__ __forceinline__ void rank_tile_of(int L, int ntiles, int ny, int& tx, int& ty) {
+    const int full = (ntiles >> 3) << 3;
+    if (L < full * ny) {
+        const int g = L / (8 * ny), r = L - g * 8 * ny;
+        tx = g * 8 + (r & 7);
+        ty = r >> 3;
+    } else {
+        const int r = L - full * ny, rem = ntiles - full;
+        ty = r / rem;
+        tx = full + r - ty * rem;
+    }
+}
+
 // Epilogue shared by the exact-fp32 and the split-bf16 loops (same accumulator layout: the C/D map of the 32x32 MFMAs does
 // not depend on the input type): FK = 0 writes the score slab, FK > 0 selects per-tile candidates.  Called after a
 // __syncthreads() that retired every read of the staging buffers (smem is reused).
@@ -245,7 +263,7 @@ __device__ __forceinline__ void cos_gemm_epilogue(f32x16 (&acc)[MT][2], float* s
                 }
                 const int qrow = m0 + h * 64 + lrow;
                 if (part == 0 && qrow < Q) {
-                    const size_t o = ((size_t)qrow * ntx + blockIdx.x + x0) * k;
+                    const size_t o = ((size_t)qrow * ntx + (size_t)(n0 / RK_BN)) * k;
 #pragma unroll
                     for (int i = 0; i < FK; ++i)
                         if (i < k) { cand_val[o + i] = ki[i] == IDX32_PAD ? NEG_INF : key_score(kv[i]); cand_idx[o + i] = ki[i]; }
@@ -281,8 +299,8 @@ template <int MT, int RK_BK, bool VEC, int FK>
 __global__ __launch_bounds__(256) void k_cos_gemm(const float* __restrict__ Qn, const float* __restrict__ Gal,
                                                   const float* __restrict__ ginv, float* __restrict__ S,
                                                   int Q, i64 G, int D, int k, float* __restrict__ cand_val,
-                                                  int* __restrict__ cand_idx, int x0, int ntx) {
-    // x0 / ntx: this launch covers the column tiles [x0, x0 + gridDim.x) of ntx (the host splits a call into a main launch
+                                                  int* __restrict__ cand_idx, int x0, int ntx, int xtiles, int ny) {
+    // x0 / ntx: this launch covers the column tiles [x0, x0 + xtiles) of ntx for ny query blocks (the host splits a call into a main launch
     // of whole rounds and a tail launch of smaller tiles)
     constexpr int BM = 64 * MT;
     constexpr int RK_LD = RK_BK + 4;      // +4 floats: ds_read_b128 of 16 distinct rows is bank-conflict free (36 and 20)
@@ -298,8 +316,10 @@ __global__ __launch_bounds__(256) void k_cos_gemm(const float* __restrict__ Qn, 
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const i64 n0 = (i64)(blockIdx.x + x0) * RK_BN;
-    const int m0 = blockIdx.y * BM;
+    int bx, by;
+    rank_tile_of((int)blockIdx.x, xtiles, ny, bx, by);
+    const i64 n0 = (i64)(bx + x0) * RK_BN;
+    const int m0 = by * BM;
 
     const int c4 = tid % CPR;  // float4 column within the K-tile
     const int r0 = tid / CPR;
@@ -417,7 +437,7 @@ __global__ __launch_bounds__(256, 3) void k_cos_gemm_split(const bf16_t* __restr
                                                            const float* __restrict__ ginv, float* __restrict__ S, int Q,
                                                            i64 G, int D, int k, float* __restrict__ cand_val,
                                                            int* __restrict__ cand_idx, int x0, int ntx, int n_steps,
-                                                           const float* __restrict__ zeros) {
+                                                           const float* __restrict__ zeros, int xtiles, int ny) {
     constexpr int BM = 64 * MT;
     constexpr int BK = 16;
     constexpr int A_STAGE = (BM / 32) * 3 * 512;      // bf16 elements per stage
@@ -433,8 +453,10 @@ __global__ __launch_bounds__(256, 3) void k_cos_gemm_split(const bf16_t* __restr
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const i64 n0 = (i64)(blockIdx.x + x0) * RK_BN;
-    const int m0 = blockIdx.y * BM;
+    int bx, by;
+    rank_tile_of((int)blockIdx.x, xtiles, ny, bx, by);
+    const i64 n0 = (i64)(bx + x0) * RK_BN;
+    const int m0 = by * BM;
     // the wave index as a scalar: piece selection becomes scalar branches (a per-lane branch around a load makes hipcc
     // drain vmcnt)
     const int swave = __builtin_amdgcn_readfirstlane(wave);
@@ -811,6 +833,32 @@ __global__ __launch_bounds__(1024) void k_cos_embedding_loss(const float* __rest
 }
 
 // An index outside [0, G) (a pad entry of a list with fewer than k real candidates) counts as a miss.
+// packed candidate lists of the sharded search (see mi355_pack_candidates / mi355_merge_packed_topk)
+__global__ __launch_bounds__(256) void k_pack_candidates(const float* __restrict__ val, const i64* __restrict__ idx, i64 Q,
+                                                         int kk, int k, int* __restrict__ packed) {
+    const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= Q * k) return;
+    const i64 q = t / k;
+    const int j = (int)(t - q * k);
+    int2 o;
+    if (j < kk) { o.x = __float_as_int(val[q * kk + j]); o.y = (int)idx[q * kk + j]; }
+    else { o.x = __float_as_int(NEG_INF); o.y = -1; }
+    reinterpret_cast<int2*>(packed)[t] = o;
+}
+
+constexpr i64 PACKED_PAD_IDX = (i64)1 << 62;    // "no candidate": sorts behind every real index at equal (-inf) score
+__global__ __launch_bounds__(256) void k_unpack_candidates(const int* __restrict__ packed, const i64* __restrict__ offsets,
+                                                           int world, i64 Q, int k, float* __restrict__ cv, i64* __restrict__ ci) {
+    const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;      // output slot: query q, candidate (r, j) = r * k + j
+    const i64 per = (i64)world * k;
+    if (t >= Q * per) return;
+    const i64 q = t / per;
+    const int c = (int)(t - q * per), r = c / k, j = c - r * k;
+    const int2 p = reinterpret_cast<const int2*>(packed)[((i64)r * Q + q) * k + j];
+    cv[t] = __int_as_float(p.x);
+    ci[t] = p.y >= 0 ? (i64)p.y + offsets[r] : PACKED_PAD_IDX;
+}
+
 __global__ void k_hit_counts(const i64* __restrict__ idx, i64 Q, int k, const i64* __restrict__ qcls,
                              const i64* __restrict__ gcls, i64 G, i64* __restrict__ counts) {
     const i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1047,16 +1095,16 @@ static int launch_gemm(const float* qn, const float* gal, const float* ginv, flo
     const int ntx = cdiv(G, RK_BN), ny = cdiv(Q, BM);
     const int xm = MT == 2 ? whole_round_tiles(ntx, ny, slots) : ntx;
     if (xm > 0) {
-        hipLaunchKernelGGL((k_cos_gemm<MT, BK, VEC, FK>), dim3((unsigned)xm, (unsigned)ny), dim3(256), lds, st, qn, gal, ginv, S,
-                           Q, G, D, k, cand_val, cand_idx, 0, ntx);
+        hipLaunchKernelGGL((k_cos_gemm<MT, BK, VEC, FK>), dim3((unsigned)xm * (unsigned)ny), dim3(256), lds, st, qn, gal, ginv, S,
+                           Q, G, D, k, cand_val, cand_idx, 0, ntx, xm, ny);
         MI355_LAUNCH_CHECK();
     }
     if (xm < ntx) {
         const size_t lds1 = gemm_lds<1, 32>(FK > 0);
         int slots1 = 0;
         if (int e = gemm_slots<1, 32, VEC, FK>(lds1, &slots1)) return e;
-        hipLaunchKernelGGL((k_cos_gemm<1, 32, VEC, FK>), dim3((unsigned)(ntx - xm), (unsigned)cdiv(Q, 64)), dim3(256), lds1, st,
-                           qn, gal, ginv, S, Q, G, D, k, cand_val, cand_idx, xm, ntx);
+        hipLaunchKernelGGL((k_cos_gemm<1, 32, VEC, FK>), dim3((unsigned)(ntx - xm) * (unsigned)cdiv(Q, 64)), dim3(256), lds1, st,
+                           qn, gal, ginv, S, Q, G, D, k, cand_val, cand_idx, xm, ntx, ntx - xm, (int)cdiv(Q, 64));
         MI355_LAUNCH_CHECK();
     }
     return OK;
@@ -1074,16 +1122,16 @@ static int launch_split(const bf16_t* qs, const float* gal, const float* ginv, f
     const float* zeros = reinterpret_cast<const float*>(qs + (size_t)cdiv(Q, 128) * 4 * n_steps * 3 * 512);
     const int xm = MT == 2 ? whole_round_tiles(ntx, ny, slots) : ntx;
     if (xm > 0) {
-        hipLaunchKernelGGL((k_cos_gemm_split<MT, FK>), dim3((unsigned)xm, (unsigned)ny), dim3(256), lds, st, qs, gal, ginv,
-                           S, Q, G, D, k, cand_val, cand_idx, 0, ntx, n_steps, zeros);
+        hipLaunchKernelGGL((k_cos_gemm_split<MT, FK>), dim3((unsigned)xm * (unsigned)ny), dim3(256), lds, st, qs, gal, ginv,
+                           S, Q, G, D, k, cand_val, cand_idx, 0, ntx, n_steps, zeros, xm, ny);
         MI355_LAUNCH_CHECK();
     }
     if (xm < ntx) {
         const size_t lds1 = split_lds<1>(FK > 0);
         int slots1 = 0;
         if (int e = split_slots<1, FK>(lds1, &slots1)) return e;
-        hipLaunchKernelGGL((k_cos_gemm_split<1, FK>), dim3((unsigned)(ntx - xm), (unsigned)cdiv(Q, 64)), dim3(256), lds1,
-                           st, qs, gal, ginv, S, Q, G, D, k, cand_val, cand_idx, xm, ntx, n_steps, zeros);
+        hipLaunchKernelGGL((k_cos_gemm_split<1, FK>), dim3((unsigned)(ntx - xm) * (unsigned)cdiv(Q, 64)), dim3(256), lds1,
+                           st, qs, gal, ginv, S, Q, G, D, k, cand_val, cand_idx, xm, ntx, n_steps, zeros, ntx - xm, (int)cdiv(Q, 64));
         MI355_LAUNCH_CHECK();
     }
     return OK;
@@ -1270,6 +1318,46 @@ int mi355_merge_topk(const float* cand_val, const int64_t* cand_idx, int64_t Q, 
     MI355_REQUIRE(workspace, "merge_topk: null workspace");
     return topk_select(cand_val, (const i64*)cand_idx, Q, ncand, ncand, k, 0, out_val, (i64*)out_idx, workspace,
                        workspace_bytes, (hipStream_t)stream);
+}
+
+// ---- packed candidates of the sharded search (sharded.py): ONE int32 tensor per rank travels through the all-gather.
+// packed[q][j] = {bits of the f32 score, LOCAL row index}; slots j >= kk (a shard with fewer than k rows) = {-inf, -1}.
+int mi355_pack_candidates(const float* val, const int64_t* idx, int64_t Q, int kk, int k, int32_t* packed, void* stream) {
+    MI355_REQUIRE(packed && Q >= 1 && k >= 1 && kk >= 0 && kk <= k, "pack_candidates: bad arguments Q=%lld kk=%d k=%d",
+                  (long long)Q, kk, k);
+    MI355_REQUIRE(kk == 0 || (val && idx), "pack_candidates: null candidates");
+    const i64 n = (i64)Q * k;
+    hipLaunchKernelGGL(k_pack_candidates, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, val,
+                       (const i64*)idx, (i64)Q, kk, k, packed);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
+// Merge of the all-gathered packed candidates [world][Q][k][2]: the shard offsets (device, int64[world]) are added here and
+// the world * k candidates of a query are merged with the rule of every other selection (higher score, then LOWER global
+// index) -> (Q, k) identical to the unsharded result.  workspace: mi355_merge_packed_workspace_bytes(Q, world, k).
+size_t mi355_merge_packed_workspace_bytes(int64_t Q, int world, int k) {
+    if (Q < 1 || world < 1 || k < 1) return 0;
+    const size_t n = (size_t)Q * world * k;
+    return align_up(n * sizeof(i64), 256) + align_up(n * sizeof(float), 256) + topk_ws_bytes(Q, (i64)world * k, k) + 512;
+}
+
+int mi355_merge_packed_topk(const int32_t* packed, const int64_t* shard_offsets, int world, int64_t Q, int k,
+                            float* out_val, int64_t* out_idx, void* workspace, size_t workspace_bytes, void* stream) {
+    MI355_REQUIRE(packed && shard_offsets && out_val && out_idx, "merge_packed_topk: null pointer");
+    MI355_REQUIRE(Q >= 1 && world >= 1 && k >= 1, "merge_packed_topk: bad shape Q=%lld world=%d k=%d", (long long)Q, world, k);
+    MI355_REQUIRE(workspace && workspace_bytes >= mi355_merge_packed_workspace_bytes(Q, world, k),
+                  "merge_packed_topk: workspace %zu < %zu bytes", workspace_bytes, mi355_merge_packed_workspace_bytes(Q, world, k));
+    const size_t n = (size_t)Q * world * k;
+    char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    i64* ci = (i64*)base;
+    float* cv = (float*)(base + align_up(n * sizeof(i64), 256));
+    char* rest = base + align_up(n * sizeof(i64), 256) + align_up(n * sizeof(float), 256);
+    hipLaunchKernelGGL(k_unpack_candidates, dim3((unsigned)cdiv((i64)n, 256)), dim3(256), 0, (hipStream_t)stream, packed,
+                       (const i64*)shard_offsets, world, (i64)Q, k, cv, ci);
+    MI355_LAUNCH_CHECK();
+    return topk_select(cv, ci, Q, (i64)world * k, (i64)world * k, k, 0, out_val, (i64*)out_idx, rest,
+                       workspace_bytes - (size_t)(rest - (char*)workspace), (hipStream_t)stream);
 }
 
 int mi355_pair_cosine(const float* a, const float* b, int64_t rows, int dim, float eps, float* out, void* stream) {

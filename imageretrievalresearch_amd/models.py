@@ -21,6 +21,8 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import operator
+import weakref
 
 import torch
 import torch.nn as nn
@@ -35,12 +37,50 @@ _FAMILY = {
 _HEAD_PATH = {"efficientnet": "classifier", "rexnet": "head.fc", "swin": "head"}
 
 
+_VERSION_OF = operator.attrgetter("_version")
+
+
 def list_models():
     return sorted(_FAMILY)
 
 
 class _Node(nn.Module):
-    """Structural container so dotted timm keys map onto real submodules."""
+    """Structural container so dotted timm keys map onto real submodules.  Replacing a parameter / buffer OBJECT on it
+    (``model.conv_stem.weight = nn.Parameter(...)``, ``torch.nn.utils.parametrize`` / ``prune``) tells the owning model, whose
+    cached tensor list would otherwise keep watching the old tensor while the packed HIP weights go stale."""
+
+    def __getitem__(self, i):          # timm's `blocks` / `features` / `layers` are nn.Sequential: model.blocks[3][2]
+        key = str(i if i >= 0 else len(self._modules) + i)
+        if key not in self._modules:
+            raise IndexError(i)
+        return self._modules[key]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def _touch_root(self):
+        ref = self.__dict__.get("_root")
+        root = ref() if ref is not None else None
+        if root is not None:
+            root.__dict__["_sig_tensors"] = None
+            root.__dict__["_dirty"] = True
+
+    def __setattr__(self, name, value):
+        if isinstance(value, (torch.Tensor, nn.Module)) or name in self._parameters or name in self._buffers:
+            self._touch_root()
+        super().__setattr__(name, value)
+
+    def __delattr__(self, name):
+        self._touch_root()
+        super().__delattr__(name)
+
+    def register_parameter(self, name, param):
+        self._touch_root()
+        super().register_parameter(name, param)
+
+    def register_buffer(self, name, tensor, persistent=True):
+        self._touch_root()
+        super().register_buffer(name, tensor, persistent=persistent)
 
 
 class ClassifierHead(nn.Module):
@@ -54,6 +94,11 @@ class ClassifierHead(nn.Module):
         self.fc = nn.Linear(in_features, num_classes) if num_classes > 0 else nn.Identity()
 
     def forward(self, x):
+        # The HIP head has no backward.  A training step (train/train.py:194-195 computes a classification loss on these
+        # logits) must not lose the head's gradient silently: refuse it the way the model's own forward does.
+        if torch.is_grad_enabled() and (x.requires_grad or (self.training and any(p.requires_grad for p in self.fc.parameters()))):
+            raise MI355Error("ClassifierHead runs in the HIP library and is forward-only (no autograd history): call it under "
+                             "torch.no_grad() / in eval mode, or train the head with torch ops on get_fm(fm)")
         return pool_linear(x, self.fc)
 
 
@@ -152,7 +197,9 @@ class MI355Model(nn.Module):
             mod = self
             for p in parts[:-1]:
                 if p not in mod._modules:
-                    mod.add_module(p, _Node())
+                    node = _Node()
+                    node.__dict__["_root"] = weakref.ref(self)
+                    mod.add_module(p, node)
                 mod = mod._modules[p]
             if kind == 0:
                 mod.register_parameter(parts[-1], nn.Parameter(torch.zeros(shape)))
@@ -239,13 +286,14 @@ class MI355Model(nn.Module):
 
     def _signature(self):
         """(storage, version) of every parameter and buffer: changes when one is written in place (optimizer step,
-        ``param.copy_``) or re-allocated.  The tensor list is cached (walking the module tree is 1.5 ms, this is 0.2 ms);
-        everything that REPLACES tensor objects (``_apply``, ``load_state_dict``, head assignment) drops the cache."""
+        ``param.copy_``) or re-allocated.  The tensor list is cached (walking the module tree is 1.5 ms, this is 0.1 ms);
+        everything that REPLACES tensor objects (``_apply``, ``load_state_dict``, head assignment, attribute assignment on
+        a sub-module: ``_Node.__setattr__``) drops the cache."""
         ts = self.__dict__.get("_sig_tensors")
         if ts is None:
             ts = list(self.parameters()) + list(self.buffers())
             self.__dict__["_sig_tensors"] = ts
-        return tuple((t.data_ptr(), t._version) for t in ts)
+        return tuple(map(torch.Tensor.data_ptr, ts)) + tuple(map(_VERSION_OF, ts))
 
     def _pack(self, device):
         L = lib()
@@ -351,7 +399,28 @@ class MI355Model(nn.Module):
         return out
 
     # ------------------------------------------------------------------ forward
+    def _refuse_training(self):
+        """The reference's training loops call the same Module (train/train.py:136,194): they would get eval-mode BatchNorm
+        outputs with no autograd history and train nothing.  Out of scope to implement, in scope to refuse."""
+        if self.training and torch.is_grad_enabled():
+            raise MI355Error(f"{self.model_name}: this backbone is forward-only (HIP kernels, eval-mode BatchNorm, no autograd "
+                             "history); call model.eval() and/or run it under torch.no_grad() - training steps such as "
+                             "train/train.py:194 are not supported")
+
+    def _custom_head(self, out):
+        """A head that is neither Linear nor Identity (user-assigned module) runs on the pooled features."""
+        head = self
+        for p in _HEAD_PATH[self.family].split("."):
+            nxt = getattr(head, p, None)
+            if nxt is None:        # e.g. rexnet `model.head = Identity()`: there is no `.fc` below it
+                break
+            head = nxt
+        if not isinstance(head, (nn.Linear, nn.Identity, ClassifierHead)):
+            out = head(out)
+        return out
+
     def _prep(self, x):
+        self._refuse_training()
         require_cuda(x, "model input")
         if x.dim() != 4 or x.shape[1] != 3:
             raise MI355Error(f"expected (B,3,H,W) input, got {tuple(x.shape)}")
@@ -386,16 +455,7 @@ class MI355Model(nn.Module):
             with torch.cuda.device(x.device):
                 check(lib().mi355_model_forward(self._handle, x.data_ptr(), B, H, W, out.data_ptr(), None,
                                                 stream_ptr(x.device)))
-        # a head that is neither Linear nor Identity (user-assigned module): apply it on the pooled features
-        head = self
-        for p in _HEAD_PATH[self.family].split("."):
-            nxt = getattr(head, p, None)
-            if nxt is None:        # e.g. rexnet `model.head = Identity()`: there is no `.fc` below it
-                break
-            head = nxt
-        if not isinstance(head, (nn.Linear, nn.Identity, ClassifierHead)):
-            out = head(out)
-        return out
+        return self._custom_head(out)
 
     def forward_uint8(self, images: torch.Tensor, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225),
                       fill: int = 255, conv_input: "nn.Module | None" = None, features: bool = False) -> torch.Tensor:
@@ -404,6 +464,7 @@ class MI355Model(nn.Module):
         -> ``conv_input`` (the ``Sequential(Conv2d(3,3,3,1,1,bias=False), SiLU)`` of inference/inference.py:103-105, or
         None) -> stem ... -> ``forward`` (or ``forward_features`` with ``features=True``).  No fp32 NCHW batch is ever
         written; bit-identical to ``preprocess.square_pad_normalize`` + ``conv_input`` + ``forward``."""
+        self._refuse_training()
         require_cuda(images, "images")
         if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[3] != 3:
             raise MI355Error(f"forward_uint8 expects uint8 (B, h, w, 3), got {images.dtype} {tuple(images.shape)}")
@@ -430,7 +491,7 @@ class MI355Model(nn.Module):
                 check(lib().mi355_model_forward_u8(self._handle, images.data_ptr(), B, h, w, int(fill), m3, s3,
                                                    cw.data_ptr() if cw is not None else None, int(features),
                                                    out.data_ptr(), None, stream_ptr(images.device)))
-        return out
+        return out if features else self._custom_head(out)
 
     def embed(self, x: torch.Tensor):
         """Pooled embeddings (B, D) regardless of the head — ``get_fm(forward_features(x))`` of

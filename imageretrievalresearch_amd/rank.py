@@ -165,6 +165,41 @@ def merge_topk(cand_val: torch.Tensor, cand_idx: torch.Tensor, k: int):
     return vals, idx
 
 
+def pack_candidates(vals: "torch.Tensor | None", idx: "torch.Tensor | None", Q: int, k: int, device) -> torch.Tensor:
+    """(Q, kk) local top-k results (kk <= k; None for an empty shard) -> (Q, k, 2) int32 {score bits, LOCAL row index},
+    missing slots = {-inf, -1}: the one tensor a rank contributes to the sharded search's candidate all-gather."""
+    packed = torch.empty((Q, k, 2), dtype=torch.int32, device=device)
+    kk = 0 if vals is None else vals.shape[1]
+    if Q:
+        v = _f32c(vals, "vals") if kk else None
+        i = idx.to(torch.int64).contiguous() if kk else None
+        with torch.cuda.device(packed.device):
+            check(lib().mi355_pack_candidates(v.data_ptr() if kk else None, i.data_ptr() if kk else None, Q, kk, k,
+                                              packed.data_ptr(), stream_ptr(packed.device)))
+    return packed
+
+
+def merge_packed_topk(packed: torch.Tensor, shard_offsets: torch.Tensor, k: int):
+    """All-gathered packed candidates (world, Q, k, 2) int32 + the shards' first global rows (world,) int64 on the device
+    -> global top-k (values (Q, k) f32, indices (Q, k) int64): offsets, unpacking and the merge run in the library."""
+    require_cuda(packed, "packed candidates")
+    if packed.dtype != torch.int32 or packed.dim() != 4 or packed.shape[3] != 2 or packed.shape[2] != k:
+        raise MI355Error(f"merge_packed_topk expects (world, Q, {k}, 2) int32, got {packed.dtype} {tuple(packed.shape)}")
+    packed = packed.contiguous()
+    world, Q = packed.shape[0], packed.shape[1]
+    off = shard_offsets.to(packed.device, torch.int64).contiguous().view(-1)
+    if off.numel() != world:
+        raise MI355Error(f"merge_packed_topk: {off.numel()} shard offsets for {world} shards")
+    vals = torch.empty((Q, k), dtype=torch.float32, device=packed.device)
+    idx = torch.empty((Q, k), dtype=torch.int64, device=packed.device)
+    if Q:
+        ws = _ws.get(packed.device, lib().mi355_merge_packed_workspace_bytes(Q, world, k))
+        with torch.cuda.device(packed.device):
+            check(lib().mi355_merge_packed_topk(packed.data_ptr(), off.data_ptr(), world, Q, k, vals.data_ptr(),
+                                                idx.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(packed.device)))
+    return vals, idx
+
+
 def pair_cosine(a: torch.Tensor, b: torch.Tensor, eps: float = _EPS) -> torch.Tensor:
     """Row-wise cos(a[i], b[i]) — inference/inference.py:226."""
     a, b = _f32c(a, "a"), _f32c(b, "b")

@@ -12,7 +12,7 @@ the one place the hot path has a real exchange step:
   4. ONE all-gather of the packed candidates (Q*k*8 bytes per rank: KBs, so latency- not link-bound; RCCL picks
      a direct one-hop exchange at this size, a ring would be 7 serial xGMI hops for nothing)
   5. every rank adds the shard offsets (a device tensor, no host sync) and merges world*k candidates per query
-     with the same ordering rule (higher score, then LOWER global index) -> identical to the single-GPU result,
+     (both inside ``mi355_merge_packed_topk``) with the same ordering rule (higher score, then LOWER global index) -> identical to the single-GPU result,
      bit for bit.
 
 world_size == 1 never touches torch.distributed.
@@ -24,7 +24,6 @@ import torch
 from . import rank as _rank
 from ._lib import MI355Error
 
-_PAD_IDX = 2 ** 62
 
 
 class _HipOps:
@@ -36,8 +35,12 @@ class _HipOps:
         return _rank.cosine_topk(queries, gallery_normalized, k, gallery_is_normalized=True, idx_offset=idx_offset)
 
     @staticmethod
-    def merge(cand_val, cand_idx, k):
-        return _rank.merge_topk(cand_val, cand_idx, k)
+    def pack(vals, idx, Q, k, device):
+        return _rank.pack_candidates(vals, idx, Q, k, device)
+
+    @staticmethod
+    def merge_packed(packed, shard_offsets, k):
+        return _rank.merge_packed_topk(packed, shard_offsets, k)
 
     @staticmethod
     def normalize(rows):
@@ -71,26 +74,19 @@ class ShardedGallery:
         for c in counts:
             self.offsets.append(self.offsets[-1] + c)
         self.total_rows = self.offsets[-1]
-        self._offsets_dev = torch.tensor(self.offsets[:-1], dtype=torch.int64, device=self.device).view(self.world, 1, 1)
+        self._offsets_dev = torch.tensor(self.offsets[:-1], dtype=torch.int64, device=self.device)
 
     @property
     def offset(self) -> int:
         return self.offsets[self.rank]
 
     def _local_candidates(self, queries, k):
-        """(Q, k, 2) int32: [..., 0] = the f32 score's bits, [..., 1] = LOCAL row index (-1 = no candidate)."""
+        """(Q, k, 2) int32: [..., 0] = the f32 score's bits, [..., 1] = LOCAL row index; a short (or empty) shard pads to
+        exactly k slots with {-inf, -1} (one library kernel: mi355_pack_candidates)."""
         Q = queries.shape[0]
-        rows = self.local.shape[0]
-        kk = min(k, rows)
-        packed = torch.empty((Q, k, 2), dtype=torch.int32, device=self.device)
-        if kk > 0:
-            v, i = self.ops.local_topk(queries, self.local, kk, 0)
-            packed[:, :kk, 0] = v.contiguous().view(torch.int32)
-            packed[:, :kk, 1] = i.to(torch.int32)
-        if kk < k:  # short (or empty) shard: pad so every rank contributes exactly k slots
-            packed[:, kk:, 0] = torch.tensor(float("-inf"), dtype=torch.float32).view(torch.int32).item()
-            packed[:, kk:, 1] = -1
-        return packed
+        kk = min(k, self.local.shape[0])
+        v, i = self.ops.local_topk(queries, self.local, kk, 0) if kk > 0 else (None, None)
+        return self.ops.pack(v, i, Q, k, self.device)
 
     def search(self, queries_local: torch.Tensor, k: int):
         """Top-k of every rank's queries against the WHOLE gallery.
@@ -110,13 +106,9 @@ class ShardedGallery:
         Q = allq.shape[0]
         allp = torch.empty((self.world * Q, k, 2), dtype=torch.int32, device=self.device)   # rank-major concat
         dist.all_gather_into_tensor(allp, packed, group=self.group)                             # the ONE candidate exchange
-        allp = allp.view(self.world, Q, k, 2)
-        gv = allp[..., 0].contiguous().view(torch.float32)
-        li = allp[..., 1].to(torch.int64)
-        gi = torch.where(li >= 0, li + self._offsets_dev, torch.full_like(li, _PAD_IDX))      # rank offset added here
-        cv = gv.permute(1, 0, 2).reshape(Q, self.world * k).contiguous()
-        ci = gi.permute(1, 0, 2).reshape(Q, self.world * k).contiguous()
-        return self.ops.merge(cv, ci, k)
+        # unpacking, the shard offsets and the merge of world * k candidates per query: one library call
+        # (mi355_merge_packed_topk), no torch elementwise kernels on the rank stream
+        return self.ops.merge_packed(allp.view(self.world, Q, k, 2), self._offsets_dev, k)
 
     def my_slice(self, Q_local: int) -> slice:
         """Rows of ``search``'s result that belong to this rank's own queries."""

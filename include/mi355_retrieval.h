@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MI355_ABI_VERSION 2
+#define MI355_ABI_VERSION 3
 
 /* ------------------------------------------------------------------ library / errors */
 int mi355_abi_version(void);
@@ -84,6 +84,17 @@ int mi355_topk_rows(const float* scores, int64_t Q, int64_t G, int k, int64_t id
 int mi355_merge_topk(const float* cand_val, const int64_t* cand_idx, int64_t Q, int ncand, int k,
                      float* out_val, int64_t* out_idx, void* workspace, size_t workspace_bytes,
                      void* stream);
+
+/* Sharded search (no reference counterpart: inference/inference.py:271 is single-device).  One int32 tensor
+ * per rank goes through the candidate all-gather: packed[q][j] = {bits of the f32 score, LOCAL row index}, slots
+ * j >= kk (a shard with fewer than k rows) = {-inf, -1}.  val / idx: (Q, kk) results of mi355_rank_topk on the shard. */
+int mi355_pack_candidates(const float* val, const int64_t* idx, int64_t Q, int kk, int k, int32_t* packed, void* stream);
+/* Merge of the all-gathered lists packed[world][Q][k][2]: adds shard_offsets[r] (device int64[world]) to rank r's local
+ * indices and selects the k best of the world * k candidates of every query (higher score, then lower global index):
+ * (Q, k) values + int64 global indices, identical to ranking against the unsharded gallery. */
+size_t mi355_merge_packed_workspace_bytes(int64_t Q, int world, int k);
+int mi355_merge_packed_topk(const int32_t* packed, const int64_t* shard_offsets, int world, int64_t Q, int k,
+                            float* out_val, int64_t* out_idx, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Row-wise pair cosine, inference/inference.py:226,229: out[i] = cos(a[i], b[i]). */
 int mi355_pair_cosine(const float* a, const float* b, int64_t rows, int dim, float eps, float* out,

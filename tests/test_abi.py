@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_loads_and_reports_version_without_gpu():
     L = _lib.lib()
-    assert L.mi355_abi_version() == 2
+    assert L.mi355_abi_version() == 3
     assert L.mi355_device_count() >= 0
     assert isinstance(L.mi355_last_error(), bytes)
 

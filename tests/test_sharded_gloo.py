@@ -27,8 +27,24 @@ class OracleOps:
         return torch.from_numpy(v), torch.from_numpy(i + idx_offset)
 
     @staticmethod
-    def merge(cand_val, cand_idx, k):
-        v, i = cand_val.numpy(), cand_idx.numpy()
+    def pack(vals, idx, Q, k, device):
+        packed = np.empty((Q, k, 2), dtype=np.int32)
+        packed[:, :, 0] = np.float32(-np.inf).view(np.int32)
+        packed[:, :, 1] = -1
+        if vals is not None:
+            kk = vals.shape[1]
+            packed[:, :kk, 0] = vals.numpy().astype(np.float32).view(np.int32)
+            packed[:, :kk, 1] = idx.numpy().astype(np.int32)
+        return torch.from_numpy(packed)
+
+    @staticmethod
+    def merge_packed(packed, shard_offsets, k):
+        p = packed.numpy()                                    # (world, Q, k, 2)
+        world, Q = p.shape[0], p.shape[1]
+        v = np.ascontiguousarray(p[..., 0]).view(np.float32).transpose(1, 0, 2).reshape(Q, world * k)
+        li = p[..., 1].astype(np.int64)
+        gi = np.where(li >= 0, li + shard_offsets.numpy().reshape(world, 1, 1), np.int64(2) ** 62)
+        i = gi.transpose(1, 0, 2).reshape(Q, world * k)
         order = np.lexsort((i, -v), axis=1)[:, :k]          # score desc, then lower global index
         return (torch.from_numpy(np.take_along_axis(v, order, 1)), torch.from_numpy(np.take_along_axis(i, order, 1)))
 

@@ -1,10 +1,18 @@
 """Per-kernel-name averages of the counters of one or more rocprofv3 --pmc passes (developer tool):
-    python tools/pmc_kernels.py <pass dir> [<pass dir> ...] > summary.json"""
+    python tools/pmc_kernels.py [--sha FINGERPRINT] [--note TEXT] <pass dir> [<pass dir> ...] > summary.json
+With --sha the output is {"csrc_sha16": ..., "note": ..., "kernels": {...}} (bench.py reports `traffic` from it only when the
+fingerprint matches the sources it runs); without it the plain {kernel: counters} map of round 2."""
 import csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_aggregate import derived
+argv = sys.argv[1:]
+sha = note = None
+while argv and argv[0] in ("--sha", "--note"):
+    if argv[0] == "--sha": sha = argv[1]
+    else: note = argv[1]
+    argv = argv[2:]
 agg = {}
-for d in sys.argv[1:]:
+for d in argv:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         per = {}
         with open(f, newline="") as fh:
@@ -28,4 +36,4 @@ for name, e in sorted(agg.items()):
         o["write_bytes"] = o["WRITE_SIZE"] * 1024.0
         o["hbm_bytes_per_launch"] = o.get("fetch_bytes_corrected", 0.0) + o["write_bytes"]
     out[name] = o
-print(json.dumps(out, indent=1))
+print(json.dumps({"csrc_sha16": sha, "note": note, "kernels": out} if sha else out, indent=1))

@@ -33,12 +33,15 @@ SQ=""; ls $OUT/pmc_sq/*/*counter_collection.csv > /dev/null 2>&1 && SQ="--sq $OU
 python tools/pmc_aggregate.py --fetch $OUT/pmc_fetch --write $OUT/pmc_write $SQ --labels $OUT/pmc_labels.json --sha "$SHA" \
   --note "efficientnet_b3a bf16 B=256 forward (tools/pmc_run.py), rocprofv3 --pmc in separate passes: FETCH_SIZE | WRITE_SIZE | SQ busy/instruction counters" \
   > $OUT/${R}_pmc_traffic_effnet_b256.json
-# rank kernel: HBM traffic + MFMA busy
+# rank kernel: HBM traffic + MFMA busy, ONE shape per run (the headline one: 256 queries x 100k rows) so that the per-kernel
+# averages are not a mix of gallery sizes (the variable is exported here, never through an `env` hop behind rocprofv3)
 cd /tmp
+export CASES=256x100000
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_rank_fetch -- python3 $ROOT/tools/bench_rank.py > $OUT/pmc_rank_fetch.log 2>&1
-rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_rank_sq -- python3 $ROOT/tools/bench_rank.py > $OUT/pmc_rank_sq.log 2>&1
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d $OUT/pmc_rank_sq -- python3 $ROOT/tools/bench_rank.py > $OUT/pmc_rank_sq.log 2>&1
+unset CASES
 cd $ROOT
-python tools/pmc_kernels.py $OUT/pmc_rank_fetch $OUT/pmc_rank_sq > $OUT/${R}_pmc_rank_kernels.json 2> $OUT/pmc_rank.err
+python tools/pmc_kernels.py --sha "$SHA" --note "tools/bench_rank.py with CASES=256x100000 (Q=256, G=100000, D=1536, k=3), rocprofv3 --pmc in separate passes; FETCH_SIZE is in KiB per dispatch, RAW (the gallery arrives as 64-byte-per-row LDS-DMA pieces: the x2 wide-read correction of fetch_bytes_corrected does not apply to it)" $OUT/pmc_rank_fetch $OUT/pmc_rank_sq > $OUT/${R}_pmc_rank_kernels.json 2> $OUT/pmc_rank.err
 # RexNet-200 and Swin-B: HBM traffic + pipe busy per kernel name
 cd /tmp
 for m in "rexnet_200 256 rexnet200" "swin_base_patch4_window7_224 128 swin_base"; do
