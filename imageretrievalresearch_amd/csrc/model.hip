@@ -363,7 +363,7 @@ static bool can_fuse_block(const mi355_model* m, size_t i, int h, int w, int nb)
     if (g.use_gate || g.res != SLOT_NONE || g.a_relu6 || !g.tap.empty() || !d.tap.empty()) return false;
     if (p.a_relu6 || p.act != ACT_NONE || (p.res != SLOT_NONE && (p.res != g.in || p.res_channels != 0))) return false;
     if (g.cin != g.cin_real || g.cout != g.cout_real || p.cout != p.cout_real) return false;   // no padded channels
-    return mbconv_block_supported(h, w, g.cin, g.cout, p.cout, d.k, d.stride, s.rd);
+    return mbconv_block_supported(h, w, g.cin, g.cout, p.cout, d.k, d.stride, s.rd, g.act, d.act);
 }
 
 // diagnosis buffer [ops][B][16] of cycle buckets (option "block_stamps"); *out stays null when the option is off
@@ -402,6 +402,8 @@ static int exec_block(ExecCtx& cx, size_t oi) {
     a.H = S[g.in].h; a.W = S[g.in].w; a.Cin = g.cin; a.Kp = (g.cin + 31) & ~31; a.mid = g.cout;
     a.Ho = S[d.out].h; a.Wo = S[d.out].w; a.Cout = p.cout; a.Kp2 = (p.cin + 31) & ~31; a.rd = s.rd;
     a.has_res = p.res != SLOT_NONE;
+    a.res_n = p.res != SLOT_NONE ? (p.res_channels ? ((p.res_channels + 7) & ~7) : p.cout) : 0;
+    a.a_relu6 = p.a_relu6;
     a.act_e = g.act; a.act_d = d.act; a.se_act = s.se_act;
     a.inv_hw = 1.0f / (float)(a.Ho * a.Wo);
     a.norot = m->block_norot;

@@ -86,13 +86,16 @@ struct BlockArgs {
     long long* stamps;                    // optional [B][8] phase cycle counts (diagnosis), may be null
     int H, W, Cin, Kp, mid, Ho, Wo, Cout, Kp2, rd;
     int XLD;                              // LDS row stride of the X image (set by the launcher)
+    int KCS;                              // k per staged super-chunk of the projection's A operand (set by the launcher)
     int norot;                            // diagnosis: bit0 slabs, bit1 SE FC1, bit2 SE FC2, bit3 projection columns NOT rotated by image
     int variant;                          // tuning (option "block_variant"): bit0 = the round-2 14x14 geometry (two waves share a channel tile, barriers per slab)
     int has_res;
+    int res_n;                            // the residual covers output channels [0, res_n) (rexnet: the block's input channels)
+    int a_relu6;                          // ReLU6 between the SE gate and the projection (rexnet)
     int act_e, act_d, se_act;
     float inv_hw;
 };
-bool mbconv_block_supported(int H, int W, int Cin, int mid, int Cout, int k, int stride, int rd);
+bool mbconv_block_supported(int H, int W, int Cin, int mid, int Cout, int k, int stride, int rd, int act_e, int act_d);
 int launch_mbconv_block(const BlockArgs& a, int B, int k, int stride, hipStream_t st);
 
 // ---- convolution-side kernels (conv_kernels.hip) -----------------------------------------------

@@ -10,7 +10,7 @@ import imageretrievalresearch_amd as M
 from imageretrievalresearch_amd import synth
 from oracle import effnet
 
-variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,1,2,3").split(",")]
+variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0").split(",")]
 Bt = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 dev = "cuda:0"
 sd = effnet.init_state_dict(2)
@@ -74,8 +74,8 @@ for v in variants:
 model.set_option("block_variant", variants[0])
 model.set_option("block_stamps", 1)
 model(x); torch.cuda.synchronize()
-print("op  | xload | wdreq mfma wdst act bar | dw bar | pool+fence fc1 fc2 | pro gate mfma bar epi | total  (kcycles, mean over images)")
+print("op  | xload expand dw tailwait fc1 fc2 proj epi | total  (kcycles of wave 0, mean over images)")
 for i, vv in model.block_stamps():
     if sum(vv) > 0 and ("@14x14" in rows[i][0] or "@7x7" in rows[i][0]):
-        print(f"{i:3d} {rows[i][0]:24s} " + " ".join(f"{c / 1e3:6.1f}" for c in vv) + f" | {sum(vv) / 1e3:7.1f}")
+        print(f"{i:3d} {rows[i][0]:24s} " + " ".join(f"{c / 1e3:6.1f}" for c in vv[:8]) + f" | {sum(vv) / 1e3:7.1f}")
 model.set_option("block_stamps", 0)

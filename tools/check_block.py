@@ -58,7 +58,7 @@ print("sum of op ms per forward", tot, {k: round(v['ms'] / 5, 3) for k, v in fam
 model.set_option("profile", 0)
 model.set_option("block_stamps", 1)
 model(x); torch.cuda.synchronize()
-print("op  | xload | wdreq mfma wdst act bar | dw bar | pool+fence fc1 fc2 | pro gate mfma bar epi | total  (kcycles, mean over images)")
+print("op  | xload expand dw tailwait fc1 fc2 proj epi | total  (kcycles of wave 0, mean over images)")
 for i, v in model.block_stamps():
-    print(f"{i:3d} {rows[i][0]:24s} " + " ".join(f"{c/1e3:6.1f}" for c in v) + f" | {sum(v)/1e3:7.1f}")
+    print(f"{i:3d} {rows[i][0]:24s} " + " ".join(f"{c/1e3:6.1f}" for c in v[:8]) + f" | {sum(v)/1e3:7.1f}")
 model.set_option("block_stamps", 0)
