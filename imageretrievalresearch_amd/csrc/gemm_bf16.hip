@@ -1083,7 +1083,9 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t st) {
     MI355_REQUIRE(!a.res || a.ldr % 4 == 0, "gemm: residual stride %d must be a multiple of 4", a.ldr);
     static const int use_splitk = getenv("MI355_GEMM_SPLITK") ? atoi(getenv("MI355_GEMM_SPLITK")) : 1;
     if (use_splitk && a.splitk_ws && !a.out_f32 && a.ldo % 4 == 0 && !a.ln_stats) {   // (the split-K reduction has no LayerNorm epilogue)
-        const int nch = gemm_splitk_chunks(a.M, a.rows_per_img > 0 ? a.rows_per_img : a.M, a.N, a.K);
+        // (decided by the caller's whole batch: split-K sums K in 256-deep chunks, i.e. rounds differently from the serial loop, and a
+        //  microbatch / lane chunk of a big batch must give the same bits as the unchunked forward)
+        const int nch = gemm_splitk_chunks(a.M_sel > 0 ? a.M_sel : a.M, a.rows_per_img > 0 ? a.rows_per_img : a.M, a.N, a.K);
         if (nch >= 2 && gemm_splitk_bytes(a.M, a.N, a.K) <= a.splitk_ws_bytes && (!a.gate || a.gate_ld % 4 == 0))
             return launch_splitk(a, nch, st);
     }

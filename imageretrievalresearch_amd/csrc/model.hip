@@ -160,7 +160,8 @@ static int pack_op(Packer& pk, Op& op) {
 static inline int conv_out(int h, int k, int s) { return (h + 2 * (k / 2) - k) / s + 1; }
 
 // Walk the plan for a chunk of nb images: fill slot dims and sizes.  Returns total arena bytes.
-static size_t plan_slots(mi355_model* m, int nb, int H, int W) {
+static size_t plan_slots(mi355_model* m, int nb, int H, int W, int B_full = 0) {
+    if (B_full < nb) B_full = nb;       // the caller's whole batch decides the kernel choices that change rounding (split-K)
     SlotState* S = m->slots;
     for (int i = 0; i < SLOT_COUNT; ++i) S[i] = SlotState();
     auto need = [&](int s, size_t bytes) { if (s != SLOT_NONE && bytes > S[s].bytes) S[s].bytes = bytes; };
@@ -175,7 +176,7 @@ static size_t plan_slots(mi355_model* m, int nb, int H, int W) {
             case OP_GEMM: {
                 const int h = S[op.in].h, w = S[op.in].w;
                 S[op.out].h = h; S[op.out].w = w; S[op.out].c = op.cout;
-                if (gemm_splitk_chunks((long)nb * h * w, h * w, op.cout, op.cin) >= 2)
+                if (gemm_splitk_chunks((long)B_full * h * w, h * w, op.cout, op.cin) >= 2)
                     need(SLOT_SPLITK, gemm_splitk_bytes((long)nb * h * w, op.cout, op.cin));
                 need(op.out, (size_t)nb * h * w * op.cout * 2);
                 break;
@@ -292,6 +293,7 @@ static int exec_op(ExecCtx& cx, const Op& op) {
             a.gate_ld = op.cin; a.rows_per_img = hw;
             a.out = cx.slot_ptr(op.out); a.ldo = op.cout; a.out_f32 = 0;
             a.M = cx.nb * hw; a.N = op.cout; a.K = op.cin;
+            a.M_sel = (long)cx.B * hw;
             a.act = op.act; a.a_relu6 = op.a_relu6;
             a.zeros = (const bf16_t*)cx.w(0);
             if (cx.ln_pending_in != SLOT_NONE) {      // the preceding LayerNorm only left (mean, rstd) per row: fold it in here
@@ -465,7 +467,8 @@ static int run_backbone(ExecCtx& cx, size_t op_begin = 0, size_t op_end = (size_
         const Op& op = m->def.ops[oi];
         const int op_index = (int)oi;
         const int in_h = S[op.in == SLOT_NONE ? 0 : op.in].h, in_w = S[op.in == SLOT_NONE ? 0 : op.in].w;
-        const bool block = op.in != SLOT_NONE && can_fuse_block(m, oi, in_h, in_w, cx.nb);
+        // (the whole-block kernel is chosen by the caller's WHOLE batch, not by the chunk: it rounds differently from the unfused chain)
+        const bool block = op.in != SLOT_NONE && can_fuse_block(m, oi, in_h, in_w, cx.B);
         const bool fused = block || can_fuse(m, oi, in_h, in_w);
         if (fused) {   // dims of the (virtual) expand output and of the depthwise output
             const Op& d = m->def.ops[oi + 1];
@@ -543,13 +546,16 @@ static int forward_impl(mi355_model* m, const float* x, int B, int H, int W, flo
     // Chunking.  "lanes" > 1: the batch is cut into that many chunks which run CONCURRENTLY on internal streams (forked from
     // and joined back into the caller's stream with events), each with its own copy of the arena: the early layers are
     // HBM-bound and the late ones VALU-bound, so two half-batches a few kernels apart keep both busy where one
-    // batch alternates between them.  Results do not depend on the chunking (every kernel is batch-position invariant).
+    // batch alternates between them.  Results do not depend on the chunking: every kernel is batch-position invariant, and the two
+    // kernel choices that round differently from their alternatives (whole-block kernel vs the unfused chain, split-K vs the serial
+    // K loop) are decided by the caller's whole batch B, never by the chunk.  (They DO depend on B itself: an image embedded alone
+    // and the same image inside a batch of 256 agree to bf16 rounding, not bit for bit - tests/test_effnet_gpu.py.)
     int nl = m->lanes;
     if (nl > 4) nl = 4;
     if (nl < 1 || B < 32 * nl || m->profile || m->taps) nl = 1;
     int mb = (m->microbatch > 0 && m->microbatch < B) ? m->microbatch : B;
     if (nl > 1) mb = (B + nl - 1) / nl;
-    const size_t bytes = plan_slots(m, mb, H, W);
+    const size_t bytes = plan_slots(m, mb, H, W, B);
     m->lane_bytes = nl > 1 ? align_up(bytes, 4096) : 0;
     if (int e = ensure_arena(m, nl > 1 ? m->lane_bytes * nl : bytes)) return e;
     if (nl > 1) {

@@ -64,7 +64,7 @@ struct mi355_model {
                                 // classes where it was measured faster than the unfused pair (see can_fuse in model.hip)
     bool fuse = true;           // fused expand+depthwise for whole-image tiles (option "fuse")
     int fuse_block = 1;         // whole MBConv block in one kernel for the 14x14 / 7x7 stages (option "fuse_block"; 0 = off)
-    int fuse_block_min_batch = 192; // ... only for chunks of at least this many images: one workgroup per image needs ~a CU per image
+    int fuse_block_min_batch = 192; // ... only when the caller's whole batch has at least this many images: one workgroup per image needs ~a CU per image
                                     // (measured B=128: 3.16 ms with, 3.01 without; B=256: 4.38 with, 4.7 without; B<=32: +0.4 ms)
     int block_variant = 0;      // tuning (option "block_variant"): see BlockArgs::variant
     int block_norot = 0;        // diagnosis (option "block_norot"): see BlockArgs::norot

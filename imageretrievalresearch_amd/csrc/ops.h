@@ -21,6 +21,7 @@ struct GemmArgs {
     int act;
     int a_relu6;
     const bf16_t* zeros;   // >= 64 bytes of device zeros (source of out-of-range DMA chunks); null disables the DMA path
+    long M_sel;            // rows of the caller's WHOLE batch (0: use M): decides split-K, so that a chunk of a larger batch rounds like the batch
     float* splitk_ws;      // optional fp32 scratch for the split-K path (gemm_splitk_bytes); null disables it
     size_t splitk_ws_bytes;
     // LayerNorm of the A rows folded into the epilogue (k_gemm_big only): out = rstd[m] * (acc - mean[m] * ln_colsum[n]) + bias[n]

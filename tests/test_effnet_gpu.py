@@ -117,6 +117,26 @@ def test_deterministic_and_batch_invariant(setup):
     assert torch.equal(a, d)
 
 
+@pytest.mark.parametrize("B,mb", [(256, 100), (200, 150), (90, 30)])
+def test_chunking_does_not_change_the_bits(setup, B, mb):
+    """the whole-block kernel (chosen from 192 images up) and the split-K projections (chosen up to 16 384 rows, i.e.
+    83 images at 14x14) round differently from their alternatives, and both used to be chosen by the CHUNK a forward is cut
+    into - a microbatch remainder or a lane embedded differently from the same image in the unchunked batch.  The choice now
+    follows the caller's whole batch: microbatches that straddle either threshold, and two concurrent lanes, give the same bits."""
+    _, model = setup
+    x = M.synth_fill(B * 3 * 224 * 224, 31, synth.UNIFORM, DEV).view(B, 3, 224, 224)
+    want = model(x).clone()
+    try:
+        model.set_option("microbatch", mb)
+        assert torch.equal(model(x), want)
+        model.set_option("microbatch", 0)
+        model.set_option("lanes", 2)
+        assert torch.equal(model(x), want)
+    finally:
+        model.set_option("microbatch", 0)
+        model.set_option("lanes", 1)
+
+
 def test_full_batch_properties_b256(setup):
     """BASELINE configs[1] size (bs = 256), through size-independent properties: run-to-run determinism, permutation
     equivariance (bit-exact: no result depends on the image's position or neighbours), and agreement with the same

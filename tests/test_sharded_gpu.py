@@ -70,3 +70,28 @@ def test_sharded_1m_gallery_matches_goldens():
     out = mgr.dict()
     mp.spawn(_worker, args=(2, port, out, "g1m", False), nprocs=2, join=True)
     assert all(out.get(r) for r in range(2)), dict(out)
+
+
+def test_bench_n2_branch_runs_and_checks_itself():
+    """The N > 1 branch of bench.py (all-gather of queries, packed candidate all-gather, library-side merge, the 64-query
+    self-check against the unsharded gallery, MAX-over-ranks timing) in fresh child processes: two gloo ranks on this
+    one GPU (RCCL refuses two ranks on one device; the driver's real N > 1 run is the first to use it).  rc must be 0 and
+    rank 0 must print one JSON line with the contract fields for n_gpus = 2."""
+    import json
+    import subprocess
+    import sys
+    from helpers import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--single-device", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] - 2 * d["config"]["batch_per_gpu"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert "roofline" in d and "cpu_baseline" not in d          # the host baseline is an N = 1 field

@@ -161,3 +161,51 @@ def test_folded_layernorm_follows_a_weight_reload():
     model.set_option("fuse_ln", 1)
     assert rel(a.cpu(), b.cpu()) < 1e-2                   # both paths see the new gamma / beta
     assert rel(a.cpu(), before.cpu()) > 5e-2              # ... and the new weights matter
+
+
+# ONE Swin block / patch merge fed the oracle's own input, relative L2 (one bf16 ulp is 3.9e-3):
+TOL_BLOCK_ISOLATED = {0: 2e-3,    # separate LayerNorm kernels = the oracle's rounding points: measured <= 1.1e-3
+                      1: 6e-3}    # LayerNorm folded into qkv / fc1: the normalised tensor is not rounded to bf16 before the product
+                                  # and the folded weights are rounded once more, measured <= 3.7e-3
+
+
+@pytest.mark.parametrize("B,fuse_ln", [(2, 1), (128, 1), (128, 0)])
+def test_each_swin_block_on_the_oracles_own_input(setup, B, fuse_ln):
+    """BASELINE configs[3] at the M where its kernels are chosen (bs = 128: the DMA GEMM's three-workgroup K = 128 form, the
+    LayerNorm folded into qkv / fc1 in every stage, the window-attention grid): each of the 24 Swin blocks and 3 patch
+    merges runs ALONE on the oracle's bf16-rounded tokens of the previous tap (mi355_model_run_between_taps).  B = 128
+    repeats the two oracle images 64 times; every repeat must be bit-identical to the first.  Both LayerNorm modes."""
+    sd, model = setup
+    x = torch.from_numpy(images(57, 2))
+    taps = {}
+    swin.forward_features(sd, x, sim_bf16=True, taps=taps)
+    order = list(taps.keys())
+    assert order[0] == "patch_embed" and len(order) == 1 + 24 + 3
+    model.set_option("fuse_ln", fuse_ln)
+    model.enable_taps(True)
+    worst = ("", 0.0)
+    try:
+        for prev, cur in zip(order[:-1], order[1:]):
+            t = taps[prev]                                          # (2, L, C) tokens
+            L, C = t.shape[1], t.shape[2]
+            side = int(round(L ** 0.5))
+            src = t.transpose(1, 2).reshape(2, C, side, side).contiguous().to(DEV)     # the (B, C, h, w) view of the token tensor
+            if B > 2:
+                src = src.repeat(B // 2, 1, 1, 1).contiguous()
+            model.run_between_taps(prev, cur, src)
+            got = model.read_tap(cur)
+            del src
+            if B > 2:
+                g = got.view(B // 2, 2, *got.shape[1:])
+                assert torch.equal(g[0], g[1]) and torch.equal(g[0], g[-1]), f"{cur}: result depends on the batch position"
+                got = g[0]
+            got = got.flatten(2).transpose(1, 2).cpu()
+            assert got.shape == taps[cur].shape, (cur, got.shape, taps[cur].shape)
+            e = rel(got, taps[cur])
+            worst = max(worst, (cur, e), key=lambda p: p[1])
+            assert e < TOL_BLOCK_ISOLATED[fuse_ln], f"{prev} -> {cur} at B={B}, fuse_ln={fuse_ln}: rel L2 {e:.3e}"
+            del got
+    finally:
+        model.enable_taps(False)
+        model.set_option("fuse_ln", 1)
+    print(f"swin B={B} fuse_ln={fuse_ln}: worst isolated block {worst}")
