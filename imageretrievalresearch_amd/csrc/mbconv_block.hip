@@ -38,7 +38,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int MB_THREADS = 512;    // 8 waves: 256 VGPRs per lane, enough to keep every global load several steps ahead
 constexpr int MB_WAVES = MB_THREADS / 64;
-constexpr int MB_MAX_RD = 128;
+constexpr int MB_MAX_RD = 192;         // SE hidden units (efficientnet_b3a <= 96, rexnet_200 <= 173)
 constexpr int MB_MC = MB_WAVES * 16;      // expanded channels per slab: one 16-channel tile per wave
 
 __device__ __forceinline__ float mb_lo(unsigned u) { return __uint_as_float(u << 16); }
@@ -814,8 +814,23 @@ static bool mb_geom(int H, int W, MbGeom* g) {
     if (W == 14 && H * W <= 208) { *g = {14, 7, 2, 3, 7, 7}; return true; }
     return false;
 }
-// expand depths (Kp / 32) the kernel is instantiated for, per map class
-static bool mb_kst_ok(int wi, int kst) { return wi == 7 ? (kst == 8 || kst == 12) : (kst == 3 || kst == 5); }
+// The instantiated kernels: (depthwise k, stride, map width, expand k-steps Kp / 32, projection column tiles per wave,
+// depthwise activation).  Every whole-block shape of the three model families at 224 x 224 is listed; anything else keeps the
+// unfused chain (a kernel of this size costs ~2 s of build time and ~40 KB of code object).
+//   efficientnet_b3a (SiLU after the depthwise conv): blocks 3.1-3.4 | 4.0 | 4.1-4.4 | 5.0 (stride 2) | 5.1-5.5 | 6.0 | 6.1
+//   rexnet_150 / rexnet_200 (linear depthwise, ReLU6 behind the SE gate, 3x3 only): 14x14 blocks 6-9 / 6-7, 7x7 blocks 12-15
+#define MB_INSTANCES(X)                                                                                              \
+    X(3, 1, 14, 3, 3, ACT_SILU) X(5, 1, 14, 3, 3, ACT_SILU) X(5, 1, 14, 5, 3, ACT_SILU) X(5, 2, 14, 5, 2, ACT_SILU)     \
+    X(5, 1, 7, 8, 2, ACT_SILU) X(3, 1, 7, 8, 3, ACT_SILU) X(3, 1, 7, 12, 3, ACT_SILU)                                 \
+    X(3, 1, 14, 4, 2, ACT_NONE) X(3, 1, 14, 4, 3, ACT_NONE) X(3, 1, 14, 5, 3, ACT_NONE) X(3, 1, 14, 6, 3, ACT_NONE)   \
+    X(3, 1, 7, 7, 2, ACT_NONE) X(3, 1, 7, 8, 2, ACT_NONE) X(3, 1, 7, 8, 3, ACT_NONE) X(3, 1, 7, 9, 3, ACT_NONE)       \
+    X(3, 1, 7, 10, 3, ACT_NONE) X(3, 1, 7, 11, 3, ACT_NONE)
+static bool mb_instance_ok(int k, int stride, int wi, int kst, int ntw, int act_d) {
+#define X(KS, S, WI, KST, NTW, AD) if (k == KS && stride == S && wi == WI && kst == KST && ntw == NTW && act_d == AD) return true;
+    MB_INSTANCES(X)
+#undef X
+    return false;
+}
 
 // Projection super-chunk: the largest multiple of the weight ring's depth (8 k-steps = 256 k, 14x14 class: 4 = 128 k) whose A image [Pout][KCS + 16] bf16
 // fits behind the gate, then balanced over the pieces.  0 = not even 256 fit.
@@ -874,7 +889,7 @@ static int mb_pick_xld(const BlockArgs& a, int k, const MbGeom& g) {
 bool mbconv_block_supported(int H, int W, int Cin, int mid, int Cout, int k, int stride, int rd, int act_e, int act_d) {
     MbGeom g;
     if (!mb_geom(H, W, &g)) return false;
-    if (act_e != ACT_SILU || (act_d != ACT_SILU && act_d != ACT_NONE)) return false;      // the instantiated activation pairs
+    if (act_e != ACT_SILU) return false;
     if (Cin % 8 || mid % 8 || mid > 2560 || Cout % 8 || rd < 1 || rd > MB_MAX_RD) return false;
     if (!((k == 3 || k == 5) && (stride == 1 || stride == 2))) return false;
     if (W == 7 && stride == 2) return false;                                 // (no 4x4 depthwise tile geometry)
@@ -885,7 +900,6 @@ bool mbconv_block_supported(int H, int W, int Cin, int mid, int Cout, int k, int
     a.Ho = (H + 2 * pad - k) / stride + 1; a.Wo = (W + 2 * pad - k) / stride + 1;
     const int Pout = a.Ho * a.Wo, MTp = (Pout + 15) / 16, NTp = (Cout + 15) / 16;
     const int ntw = mb_proj_ntw(NTp, MTp, g.ntw);
-    if (ntw != 2 && ntw != 3) return false;                                  // the instantiated projection widths
     const int nwn = (NTp + ntw - 1) / ntw;
     if (nwn > MB_WAVES) return false;
     int msplit = MB_WAVES / nwn;
@@ -894,7 +908,7 @@ bool mbconv_block_supported(int H, int W, int Cin, int mid, int Cout, int k, int
     a.Kp2 = (mid + 31) & ~31;
     if (Pout * (g.wi == 7 ? 32 : 16) > g.a_it * MB_THREADS) return false;   // chunked projection: staged pieces per thread per K chunk
     if ((H * W + 15) / 16 > g.mw * g.mh) return false;
-    if (!mb_kst_ok(g.wi, a.Kp / 32)) return false;
+    if (!mb_instance_ok(k, stride, g.wi, a.Kp / 32, ntw, act_d)) return false;
     return mb_pick_xld(a, k, g) != 0;
 }
 
@@ -918,40 +932,18 @@ static int launch_mb(BlockArgs a, int B, hipStream_t st) {
     return OK;
 }
 
-// column tiles per wave of the projection (the kernel's NTW is exact)
-static int mb_ntw_of(const BlockArgs& a) {
-    const int Pout = a.Ho * a.Wo;
-    return mb_proj_ntw((a.Cout + 15) / 16, (Pout + 15) / 16, 3);
-}
-
-template <int KS, int S, int ACT_D, int NTW>
-static int launch_mb_ntw(const BlockArgs& a, int B, hipStream_t st) {
-    if (a.W == 7) {
-        if (a.Kp == 256) return launch_mb<KS, S, 7, 4, 1, NTW, 4, 8, 4, ACT_SILU, ACT_D>(a, B, st);
-        return launch_mb<KS, S, 7, 4, 1, NTW, 4, 12, 4, ACT_SILU, ACT_D>(a, B, st);
-    }
-    if (a.Kp == 96) return launch_mb<KS, S, 14, 7, 2, NTW, 7, 3, 7, ACT_SILU, ACT_D>(a, B, st);
-    return launch_mb<KS, S, 14, 7, 2, NTW, 7, 5, 7, ACT_SILU, ACT_D>(a, B, st);
-}
-template <int KS, int S, int ACT_D>
-static int launch_mb_ks(const BlockArgs& a, int B, hipStream_t st) {
-    const int ntw = mb_ntw_of(a);
-    if (ntw == 3) return launch_mb_ntw<KS, S, ACT_D, 3>(a, B, st);
-    MI355_REQUIRE(ntw == 2, "mbconv_block: no instantiation for %d column tiles per wave", ntw);
-    return launch_mb_ntw<KS, S, ACT_D, 2>(a, B, st);
-}
-
 int launch_mbconv_block(const BlockArgs& a, int B, int k, int stride, hipStream_t st) {
     MI355_REQUIRE(mbconv_block_supported(a.H, a.W, a.Cin, a.mid, a.Cout, k, stride, a.rd, a.act_e, a.act_d), "mbconv_block: unsupported shape");
-    if (a.act_d == ACT_SILU) {            // efficientnet (k = 3 / 5)
-        if (k == 3 && stride == 1) return launch_mb_ks<3, 1, ACT_SILU>(a, B, st);
-        if (k == 3 && stride == 2) return launch_mb_ks<3, 2, ACT_SILU>(a, B, st);
-        if (k == 5 && stride == 1) return launch_mb_ks<5, 1, ACT_SILU>(a, B, st);
-        return launch_mb_ks<5, 2, ACT_SILU>(a, B, st);
-    }
-    MI355_REQUIRE(k == 3, "mbconv_block: the linear-depthwise (rexnet) variant is built for 3x3 only");
-    if (stride == 1) return launch_mb_ks<3, 1, ACT_NONE>(a, B, st);
-    return launch_mb_ks<3, 2, ACT_NONE>(a, B, st);
+    const int Pout = a.Ho * a.Wo;
+    const int ntw = mb_proj_ntw((a.Cout + 15) / 16, (Pout + 15) / 16, 3);      // column tiles per wave of the projection (the kernel's NTW is exact)
+    const int kst = a.Kp / 32;
+#define X(KS, S, WI, KST, NTW, AD)                                                                  \
+    if (k == KS && stride == S && a.W == WI && kst == KST && ntw == NTW && a.act_d == AD)           \
+        return launch_mb<KS, S, WI, (WI == 7 ? 4 : 7), (WI == 7 ? 1 : 2), NTW, (WI == 7 ? 4 : 7), KST, (WI == 7 ? 4 : 7), ACT_SILU, AD>(a, B, st);
+    MB_INSTANCES(X)
+#undef X
+    set_error("mbconv_block: no instance for k=%d s=%d W=%d Kp=%d ntw=%d", k, stride, a.W, a.Kp, ntw);
+    return ERR_UNSUPPORTED;
 }
 
 }  // namespace mi355

@@ -363,8 +363,10 @@ static bool can_fuse_block(const mi355_model* m, size_t i, int h, int w, int nb)
     if (g.kind != OP_GEMM || d.kind != OP_DW || s.kind != OP_SE || p.kind != OP_GEMM) return false;
     if (g.out != SLOT_E || d.in != SLOT_E || d.out != SLOT_D || p.in != SLOT_D || !p.use_gate || !d.pool) return false;
     if (g.use_gate || g.res != SLOT_NONE || g.a_relu6 || !g.tap.empty() || !d.tap.empty()) return false;
-    if (p.a_relu6 || p.act != ACT_NONE || (p.res != SLOT_NONE && (p.res != g.in || p.res_channels != 0))) return false;
-    if (g.cin != g.cin_real || g.cout != g.cout_real || p.cout != p.cout_real) return false;   // no padded channels
+    // (rexnet: ReLU6 behind the gate, a shortcut over the first res_channels outputs and channel counts padded to 8 are all
+    //  handled by the kernel: pad channels carry exact zeros through every phase, as in the unfused chain)
+    if (p.act != ACT_NONE || (p.res != SLOT_NONE && p.res != g.in)) return false;
+    if (p.res != SLOT_NONE && p.res_channels && ((p.res_channels + 7) & ~7) != g.cin) return false;
     return mbconv_block_supported(h, w, g.cin, g.cout, p.cout, d.k, d.stride, s.rd, g.act, d.act);
 }
 
