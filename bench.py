@@ -206,6 +206,11 @@ def main():
         q = M.synth_fill(a.batch * D, 13, synth.NORMAL, dev).view(a.batch, D)
         t_rank = timeit(lambda: gal.ops.local_topk(q, gal.local, TOPK, 0), n_side)
         t_rank1 = timeit(lambda: gal.ops.local_topk(q[:1], gal.local, TOPK, 0), n_side)   # the reference's per-query call shape
+        # side metric: the same search against the shard held as the GEMM's bf16 planes (mi355_gallery_prepare: +6 B per element
+        # of HBM, no per-call split of the gallery; results identical bit for bit).  `value` uses the fp32 rows.
+        prep = M.PreparedGallery(gal.local)
+        t_rank_prep = timeit(lambda: prep.search(q, TOPK), n_side)
+        del prep
 
         # ---- roofline of the dominant KERNEL: hipEvents around every launch, on the launch stream.  A launch that runs
         # several ops of the plan (expand + depthwise, or a whole MBConv block) carries the layer-granular bytes of all of them.
@@ -305,6 +310,7 @@ def main():
                        "parallelism": f"dp{world} + row-sharded gallery", "streams": "embed || rank (2 HIP streams)" if a.streams == 2 else "one HIP stream"},
             "embed_images_per_s_1gpu": a.batch / t_embed,
             "rank_queries_per_s_1gpu_shard": a.batch / t_rank,
+            "rank_queries_per_s_1gpu_shard_prepared_gallery": a.batch / t_rank_prep,
             "embed_roofline": {"algorithmic_GBps": embed_gbs, "frac_of_8TBps": embed_gbs / HBM_PEAK_GBS,
                                "act_MB_per_img": tr["act_bytes"] / a.batch / 1e6,
                                "gflop_per_img": 2 * tr["macs"] / a.batch / 1e9},

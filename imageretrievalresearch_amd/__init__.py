@@ -9,12 +9,12 @@ for device memory, streams and torch.distributed only.
 from . import synth  # noqa: F401
 from ._lib import MI355Error, lib, LIB_PATH  # noqa: F401
 from . import models  # noqa: F401
-from .rank import (ContrastiveLoss, CosineEmbeddingLoss, CosineSimilarity, Gallery, cos_sim_score_booster,  # noqa: F401
+from .rank import (ContrastiveLoss, CosineEmbeddingLoss, CosineSimilarity, Gallery, PreparedGallery, cos_sim_score_booster,  # noqa: F401
                    cos_sim_score_with_threshold, cosine_scores, cosine_topk,
                    distinct_class_topn, hit_counts, l2_normalize_rows, merge_topk, pair_cosine,
                    retrieval_metrics, synth_fill, topk, validation_metrics)
 
-__all__ = ["create_model", "list_models", "load_checkpoint", "strip_lightning_prefix", "ContrastiveLoss", "CosineEmbeddingLoss", "validation_metrics", "CosineSimilarity", "Gallery", "cosine_scores",
+__all__ = ["create_model", "list_models", "load_checkpoint", "strip_lightning_prefix", "ContrastiveLoss", "CosineEmbeddingLoss", "validation_metrics", "CosineSimilarity", "Gallery", "PreparedGallery", "cosine_scores",
            "cosine_topk", "pair_cosine", "topk", "merge_topk", "hit_counts", "distinct_class_topn",
            "retrieval_metrics", "cos_sim_score_with_threshold", "cos_sim_score_booster", "l2_normalize_rows", "synth_fill", "ShardedGallery", "MI355Error"]
 

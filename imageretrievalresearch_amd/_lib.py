@@ -27,6 +27,10 @@ PROTOTYPES = {
     "mi355_rank_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int, C.c_int]),
     "mi355_rank_topk": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float,
                                   C.c_int64, vp, vp, vp, C.c_size_t, vp]),
+    "mi355_gallery_planes_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "mi355_gallery_prepare": (C.c_int, [vp, C.c_int64, C.c_int, vp, C.c_size_t, vp]),
+    "mi355_rank_topk_prepared": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_int64, vp, vp, vp,
+                                           C.c_size_t, vp]),
     "mi355_cosine_scores": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_int, C.c_float, vp, vp,
                                       C.c_size_t, vp]),
     "mi355_topk_rows": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int, C.c_int64, vp, vp, vp, C.c_size_t, vp]),

@@ -595,6 +595,139 @@ __global__ __launch_bounds__(256, 3) void k_cos_gemm_split(const bf16_t* __restr
 }
 
 // =====================================================================================
+// The same GEMM against a PREPARED gallery (mi355_gallery_prepare): the resident gallery holds, beside nothing else, the three
+// bf16 planes of its normalised rows in the fragment order of k_split_queries ([row block of 32][k step][h, m, l][64 lanes][8],
+// 6 B per element instead of 4).  Both operands then arrive by LDS-DMA as ready MFMA fragments: no split in the loop (round 2's
+// PMC: matrix pipe 57 % busy + VALU 45 % busy, the 88 VALU instructions per fragment split did not co-issue with the MFMAs).
+// Per k-step a workgroup moves 12 A pieces (one k-step ahead, from L2) and 12 B pieces (two ahead, from HBM), three + three per
+// wave; ONE counted vmcnt (the three youngest = this iteration's B pieces stay in flight) + one LDS-only barrier per k-step.
+// Scores are bit-identical to k_cos_gemm_split: the planes are the same values (split3 of the same fp32 rows) and the six
+// products are accumulated in the same order.  LDS: 2 x 12 KB (A) + 3 x 12 KB (B) = 60 KB at MT = 2 (two workgroups per CU).
+// =====================================================================================
+template <int MT, int FK>
+__global__ __launch_bounds__(256, 2) void k_cos_gemm_pre(const bf16_t* __restrict__ Qs, const bf16_t* __restrict__ Gs,
+                                                         float* __restrict__ S, int Q, i64 G, int k,
+                                                         float* __restrict__ cand_val, int* __restrict__ cand_idx, int x0,
+                                                         int ntx, int n_steps, int xtiles, int ny) {
+    constexpr int BM = 64 * MT;
+    constexpr int A_PIECES = (BM / 32) * 3;           // 1 KB pieces per stage
+    constexpr int A_STAGE = A_PIECES * 512;           // bf16 elements per stage
+    constexpr int B_PIECES = (RK_BN / 32) * 3;        // 12
+    constexpr int B_STAGE = B_PIECES * 512;
+    constexpr int A_RING = MT == 1 ? 3 : 2;           // (MT = 1: the tail launch / small-Q shapes, nothing else hides a piece's latency)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    bf16_t* As = reinterpret_cast<bf16_t*>(smem);                       // [A_RING][BM/32][3][512]
+    bf16_t* Bs = As + A_RING * A_STAGE;                                 // [3][4][3][512]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bx, by;
+    rank_tile_of((int)blockIdx.x, xtiles, ny, bx, by);
+    const i64 n0 = (i64)(bx + x0) * RK_BN;
+    const int m0 = by * BM;
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+
+    // piece (row block rbl, plane p) of k-step t sits at base + (((row0/32 + rbl) * n_steps + t) * 3 + p) * 512; wave w moves
+    // pieces w, w + 4, w + 8 of a 12-piece stage (MT = 1, A: pieces w and (w < 2) w + 4)
+    const bf16_t* a_src = Qs + (size_t)(m0 / 32) * n_steps * 3 * 512 + lane * 8;
+    const bf16_t* b_src = Gs + (size_t)(n0 / 32) * n_steps * 3 * 512 + lane * 8;
+    const bf16_t* a_piece[(A_PIECES + 3) / 4];
+    const bf16_t* b_piece[3];
+#pragma unroll
+    for (int i = 0; i < (A_PIECES + 3) / 4; ++i) {
+        const int piece = (swave + 4 * i) % A_PIECES;
+        a_piece[i] = a_src + ((size_t)((piece / 3) * n_steps) * 3 + piece % 3) * 512;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int piece = swave + 4 * i;
+        b_piece[i] = b_src + ((size_t)((piece / 3) * n_steps) * 3 + piece % 3) * 512;
+    }
+    auto dma_a = [&](int buf, int t) {
+#pragma unroll
+        for (int i = 0; i < (A_PIECES + 3) / 4; ++i) {
+            const int piece = swave + 4 * i;
+            if (A_PIECES % 4 == 0 || i < A_PIECES / 4 || swave < A_PIECES % 4)
+                glds16(a_piece[i] + (size_t)t * 3 * 512, As + buf * A_STAGE + piece * 512);
+        }
+    };
+    // (k-steps past the end re-read the last one: the data is never used, the count of pieces in flight stays uniform)
+    auto dma_b = [&](int stage, int t) {
+        const int tt = t < n_steps ? t : n_steps - 1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) glds16(b_piece[i] + (size_t)tt * 3 * 512, Bs + stage * B_STAGE + (swave + 4 * i) * 512);
+    };
+
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto compute = [&](int abuf, int bstage) {
+        const bf16_t* a = As + abuf * A_STAGE + (wm * MT * 3) * 512 + lane * 8;
+        const bf16_t* b = Bs + bstage * B_STAGE + (wn * 2 * 3) * 512 + lane * 8;
+        bf16x8 af[MT][3], bfr[2][3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bfr[j][p] = *reinterpret_cast<const bf16x8*>(b + (j * 3 + p) * 512);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(a + (i * 3 + p) * 512);
+        // six products per (row block, gallery fragment), smallest terms first - the order of k_cos_gemm_split
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bfr[j][0], acc[i][j], 0, 0, 0);   // l * h'
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][2], acc[i][j], 0, 0, 0);   // h * l'
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][1], acc[i][j], 0, 0, 0);   // m * m'
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][0], acc[i][j], 0, 0, 0);   // m * h'
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][1], acc[i][j], 0, 0, 0);   // h * m'
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][0], acc[i][j], 0, 0, 0);   // h * h'
+            }
+    };
+
+    dma_a(0, 0);
+    if (A_RING == 3 && n_steps > 1) dma_a(1, 1);
+    dma_b(0, 0);
+    dma_b(1, 1);
+    __syncthreads();                   // drains vmcnt: everything has landed
+
+    int bs_cur = 0, bs_far = 2;        // B stage of k-step t / of k-step t + 2 (and, at A_RING == 3, the A stages)
+    for (int t = 0; t < n_steps; ++t) {
+        if constexpr (A_RING == 2) {
+            if (t + 1 < n_steps) dma_a((t & 1) ^ 1, t + 1);  // everybody left these buffers at the previous barrier
+        } else {
+            if (t + 2 < n_steps) dma_a(bs_far, t + 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);                   // (the counts below need the A pieces issued BEFORE the B pieces)
+        dma_b(bs_far, t + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(A_RING == 2 ? (t & 1) : bs_cur, bs_cur);
+        if constexpr (A_RING == 2) {
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); // A(t+1) and B(t+1) have landed; the three B(t+2) pieces stay in flight
+        } else {
+            // A(t+2) (two pieces from waves 0 and 1, one from waves 2 and 3; none at the end) and B(t+2) stay in flight
+            if (t + 2 >= n_steps) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (swave < A_PIECES % 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        bs_cur = bs_cur == 2 ? 0 : bs_cur + 1;
+        bs_far = bs_far == 2 ? 0 : bs_far + 1;
+    }
+    __syncthreads();                   // the last look-ahead pieces have landed before the epilogue reuses the LDS
+    cos_gemm_epilogue<MT, FK>(acc, smem, nullptr, S, Q, G, k, cand_val, cand_idx, x0, ntx, n0, m0);
+}
+
+// =====================================================================================
 // few queries (Q <= 4, the reference's own per-query call shape cos(q[None], G), train/train.py:250): a GEMM tile
 // would be 98 % padding; this is a GEMV, bound by streaming the gallery once (4*D bytes per row).  One wave per
 // gallery row (6 KB contiguous for D = 1536), the normalised queries sit in LDS, two rows in flight per wave.
@@ -1156,6 +1289,49 @@ static int launch_split_fk(const bf16_t* qs, const float* gal, const float* ginv
     return launch_split<MT, 8>(qs, gal, ginv, S, Q, G, D, k, cand_val, cand_idx, st);
 }
 
+template <int MT>
+static size_t pre_lds(bool fk) {
+    const size_t stage = (size_t)(MT == 1 ? 3 : 2) * (64 * MT / 32) * 3 * 1024 + (size_t)3 * (RK_BN / 32) * 3 * 1024;   // A ring of 2 (3 at MT = 1), B ring of 3
+    const size_t tile = fk ? (size_t)64 * (RK_BN + 4) * sizeof(float) : 0;
+    return stage > tile ? stage : tile;
+}
+template <int MT, int FK>
+static int pre_slots(size_t lds, int* slots_out) {
+    static int slots[MI355_MAX_DEVICES] = {0};
+    return kernel_slots((const void*)k_cos_gemm_pre<MT, FK>, lds, slots, slots_out);
+}
+// prepared gallery: qs = the split planes of these Q queries, gs = the gallery's planes (whole 128-row tiles)
+template <int MT, int FK>
+static int launch_pre(const bf16_t* qs, const bf16_t* gs, int Q, i64 G, int D, int k, float* cand_val, int* cand_idx, hipStream_t st) {
+    constexpr int BM = 64 * MT;
+    const size_t lds = pre_lds<MT>(FK > 0);
+    int slots = 0;
+    if (int e = pre_slots<MT, FK>(lds, &slots)) return e;
+    const int ntx = cdiv(G, RK_BN), ny = cdiv(Q, BM), n_steps = cdiv(D, 16);
+    const int xm = MT == 2 ? whole_round_tiles(ntx, ny, slots) : ntx;
+    if (xm > 0) {
+        hipLaunchKernelGGL((k_cos_gemm_pre<MT, FK>), dim3((unsigned)xm * (unsigned)ny), dim3(256), lds, st, qs, gs, (float*)nullptr, Q, G, k,
+                           cand_val, cand_idx, 0, ntx, n_steps, xm, ny);
+        MI355_LAUNCH_CHECK();
+    }
+    if (xm < ntx) {
+        const size_t lds1 = pre_lds<1>(FK > 0);
+        int slots1 = 0;
+        if (int e = pre_slots<1, FK>(lds1, &slots1)) return e;
+        hipLaunchKernelGGL((k_cos_gemm_pre<1, FK>), dim3((unsigned)(ntx - xm) * (unsigned)cdiv(Q, 64)), dim3(256), lds1, st, qs, gs,
+                           (float*)nullptr, Q, G, k, cand_val, cand_idx, xm, ntx, n_steps, ntx - xm, (int)cdiv(Q, 64));
+        MI355_LAUNCH_CHECK();
+    }
+    return OK;
+}
+template <int MT>
+static int launch_pre_fk(const bf16_t* qs, const bf16_t* gs, int Q, i64 G, int D, int k, float* cand_val, int* cand_idx, hipStream_t st) {
+    if (k <= 1) return launch_pre<MT, 1>(qs, gs, Q, G, D, k, cand_val, cand_idx, st);
+    if (k <= 2) return launch_pre<MT, 2>(qs, gs, Q, G, D, k, cand_val, cand_idx, st);
+    if (k <= 4) return launch_pre<MT, 4>(qs, gs, Q, G, D, k, cand_val, cand_idx, st);
+    return launch_pre<MT, 8>(qs, gs, Q, G, D, k, cand_val, cand_idx, st);
+}
+
 // MI355_RANK_EXACT_F32=1 keeps the GEMM on v_mfma_f32_32x32x2_f32 (a bit-for-bit fmaf chain, 2.7x the matrix-pipe time);
 // the default is the three-way bf16 split with six products (fp32-equivalent, see split3).
 static bool rank_exact_f32() {
@@ -1297,6 +1473,68 @@ int mi355_rank_topk(const float* queries, int64_t Q, const float* gallery, int64
         if (int e = cos_gemm(w.qn + qs * dim, w.qs, gallery, ginv, w.S, qn, G, dim, st)) return e;
         if (int e = topk_select(w.S, nullptr, qn, G, G, k, idx_offset, out_val + qs * k, (i64*)out_idx + qs * k,
                                 w.topk, w.topk_bytes, st))
+            return e;
+    }
+    return OK;
+}
+
+// ---- prepared gallery (resident galleries: Gallery / ShardedGallery hold it next to nothing else for k <= 8 searches)
+// planes of the NORMALISED rows, in the fragment order of the GEMM's B operand: whole 128-row tiles, 16-deep k steps, 6 B per element
+size_t mi355_gallery_planes_bytes(int64_t G, int dim) {
+    if (G < 1 || dim < 1) return 0;
+    return split_queries_bytes(G, dim);
+}
+
+int mi355_gallery_prepare(const float* gallery_normalized, int64_t G, int dim, void* planes, size_t planes_bytes, void* stream) {
+    MI355_REQUIRE(gallery_normalized && planes, "gallery_prepare: null pointer");
+    MI355_REQUIRE(G >= 1 && dim >= 1 && G < ((int64_t)1 << 31) - RK_BN, "gallery_prepare: bad shape G=%lld dim=%d", (long long)G, dim);
+    MI355_REQUIRE(planes_bytes >= mi355_gallery_planes_bytes(G, dim), "gallery_prepare: planes buffer %zu < %zu bytes", planes_bytes,
+                  mi355_gallery_planes_bytes(G, dim));
+    const int n_steps = cdiv(dim, 16);
+    const i64 n_frag = (i64)cdiv(G, 128) * 4 * n_steps;
+    MI355_REQUIRE(n_frag < ((i64)1 << 31), "gallery_prepare: gallery too large for one call");
+    hipLaunchKernelGGL(k_split_queries, dim3((unsigned)cdiv(n_frag, 4)), dim3(256), 0, (hipStream_t)stream, gallery_normalized,
+                       (bf16_t*)planes, (int)G, dim, n_steps, (int)n_frag);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
+// mi355_rank_topk against a prepared gallery (rows normalised when the planes were made): k <= 8, Q > 4 (the fused selection's
+// range; other shapes go through mi355_rank_topk with the fp32 rows).  Scores and indices are bit-identical to
+// mi355_rank_topk(gallery_is_normalized = 1) on the same rows.  workspace: mi355_rank_workspace_bytes(Q, G, dim, k).
+int mi355_rank_topk_prepared(const float* queries, int64_t Q, const void* gallery_planes, int64_t G, int dim, int k, float eps,
+                             int64_t idx_offset, float* out_val, int64_t* out_idx, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+    MI355_REQUIRE(queries && gallery_planes && out_val && out_idx, "rank_topk_prepared: null pointer");
+    MI355_REQUIRE(Q >= 1 && G >= 1 && dim >= 1, "rank_topk_prepared: bad shape Q=%lld G=%lld dim=%d", (long long)Q, (long long)G, dim);
+    MI355_REQUIRE(k >= 1 && k <= G, "rank_topk_prepared: k=%d outside [1, %lld]", k, (long long)G);
+    MI355_REQUIRE(fused_select(Q, G, k), "rank_topk_prepared: needs k <= %d and more than 4 queries (got k=%d, Q=%lld)", SMALL_K, k, (long long)Q);
+    hipStream_t st = (hipStream_t)stream;
+    RankWs w = carve(workspace, Q, G, dim, k, false);
+    MI355_REQUIRE(workspace && workspace_bytes >= w.total, "rank_topk_prepared: workspace %zu < %zu bytes", workspace_bytes, w.total);
+    const int vq = vec_ok(queries, dim) && vec_ok(w.qn, dim);
+    {
+        RoctxRange range("rank/normalize");
+        hipLaunchKernelGGL((k_row_norm<true>), dim3((unsigned)cdiv(Q, 4)), dim3(256), 0, st, queries, w.qn, (float*)nullptr, (i64)Q, dim, eps, vq);
+        MI355_LAUNCH_CHECK();
+    }
+    const i64 qb = query_block(Q, G, k);
+    const i64 ntiles = cdiv(G, RK_BN);
+    const int n_steps = cdiv(dim, 16);
+    for (i64 qs = 0; qs < Q; qs += qb) {
+        const i64 qn = (Q - qs < qb) ? Q - qs : qb;
+        {
+            RoctxRange range("rank/cosine gemm (prepared gallery) + per-tile top-k");
+            const int n_frag = cdiv(qn, 128) * 4 * n_steps;
+            hipLaunchKernelGGL(k_split_queries, dim3((unsigned)cdiv(n_frag, 4)), dim3(256), 0, st, w.qn + qs * dim, w.qs, (int)qn, dim, n_steps, n_frag);
+            MI355_LAUNCH_CHECK();
+            const int e = qn > 64 ? launch_pre_fk<2>(w.qs, (const bf16_t*)gallery_planes, (int)qn, G, dim, k, w.cand_val, w.cand_idx, st)
+                                  : launch_pre_fk<1>(w.qs, (const bf16_t*)gallery_planes, (int)qn, G, dim, k, w.cand_val, w.cand_idx, st);
+            if (e) return e;
+        }
+        RoctxRange range("rank/merge candidates");
+        if (int e = topk_select(w.cand_val, nullptr, qn, ntiles * k, ntiles * k, k, idx_offset, out_val + qs * k,
+                                (i64*)out_idx + qs * k, w.topk, w.topk_bytes, st, w.cand_idx))
             return e;
     }
     return OK;

@@ -124,6 +124,47 @@ def cosine_topk(queries: torch.Tensor, gallery: torch.Tensor, k: int, eps: float
     return vals, idx
 
 
+class PreparedGallery:
+    """The three bf16 planes of a gallery's NORMALISED rows in the cosine GEMM's fragment order (6 B per element): made once
+    for a resident gallery (``mi355_gallery_prepare``), so that a search does no per-call work on the gallery side - the
+    reference re-reads and re-normalises the whole gallery for every query (train/train.py:250)."""
+
+    def __init__(self, gallery_normalized: torch.Tensor):
+        g = _f32c(gallery_normalized, "gallery")
+        if g.dim() != 2 or g.shape[0] < 1:
+            raise MI355Error(f"a prepared gallery needs (G, D) rows with G >= 1, got {tuple(g.shape)}")
+        self.rows, self.dim, self.device = int(g.shape[0]), int(g.shape[1]), g.device
+        nbytes = lib().mi355_gallery_planes_bytes(self.rows, self.dim)
+        self.planes = torch.empty((nbytes,), dtype=torch.uint8, device=g.device)
+        with torch.cuda.device(g.device):
+            check(lib().mi355_gallery_prepare(g.data_ptr(), self.rows, self.dim, self.planes.data_ptr(), nbytes,
+                                              stream_ptr(g.device)))
+
+    @staticmethod
+    def supports(Q: int, k: int) -> bool:
+        """The prepared path covers the fused selection's range; other shapes use the fp32 rows (``cosine_topk``)."""
+        return Q > 4 and 1 <= k <= 8
+
+    def search(self, queries: torch.Tensor, k: int, eps: float = _EPS, idx_offset: int = 0):
+        """``cosine_topk(queries, rows, k, gallery_is_normalized=True)`` - same values and indices, bit for bit."""
+        q = _f32c(queries, "queries")
+        if q.dim() != 2 or q.shape[1] != self.dim:
+            raise MI355Error(f"queries must be (Q,{self.dim}), got {tuple(q.shape)}")
+        Q = q.shape[0]
+        if k > self.rows or k < 1:
+            raise MI355Error(f"selected index k out of range: k={k}, gallery rows={self.rows}")
+        if not self.supports(Q, k):
+            raise MI355Error(f"prepared search needs k <= 8 and more than 4 queries (got k={k}, Q={Q}): use cosine_topk on the rows")
+        vals = torch.empty((Q, k), dtype=torch.float32, device=q.device)
+        idx = torch.empty((Q, k), dtype=torch.int64, device=q.device)
+        ws = _ws.get(q.device, lib().mi355_rank_workspace_bytes(Q, self.rows, self.dim, k))
+        with torch.cuda.device(q.device):
+            check(lib().mi355_rank_topk_prepared(q.data_ptr(), Q, self.planes.data_ptr(), self.rows, self.dim, k, eps,
+                                                 int(idx_offset), vals.data_ptr(), idx.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                 stream_ptr(q.device)))
+        return vals, idx
+
+
 def topk(scores: torch.Tensor, k: int, idx_offset: int = 0):
     """``torch.topk(sim, k)`` over the last dim of a 1-D or 2-D fp32 score tensor."""
     squeeze = scores.dim() == 1
@@ -392,7 +433,17 @@ class Gallery:
     def __len__(self):
         return self.rows
 
+    def prepare(self):
+        """Split the resident rows once into the GEMM's bf16 planes (PreparedGallery, +6 B per element): searches with k <= 8
+        and more than 4 queries then run without touching the fp32 rows.  Call again after ``add``."""
+        self._prepared = PreparedGallery(self.data) if self.rows else None
+        self._prepared_rows = self.rows
+        return self
+
     def search(self, queries: torch.Tensor, k: int, idx_offset: int = 0):
+        p = getattr(self, "_prepared", None)
+        if p is not None and self._prepared_rows == self.rows and PreparedGallery.supports(queries.shape[0], k):
+            return p.search(queries, k, self.eps, idx_offset)
         return cosine_topk(queries, self.data, k, self.eps, gallery_is_normalized=True, idx_offset=idx_offset)
 
 

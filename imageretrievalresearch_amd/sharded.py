@@ -31,8 +31,14 @@ class _HipOps:
     collective plumbing under gloo without a GPU; the product path is always this one.)"""
 
     @staticmethod
-    def local_topk(queries, gallery_normalized, k, idx_offset):
+    def local_topk(queries, gallery_normalized, k, idx_offset, prepared=None):
+        if prepared is not None and _rank.PreparedGallery.supports(queries.shape[0], k):
+            return prepared.search(queries, k, idx_offset=idx_offset)
         return _rank.cosine_topk(queries, gallery_normalized, k, gallery_is_normalized=True, idx_offset=idx_offset)
+
+    @staticmethod
+    def prepare(gallery_normalized):
+        return _rank.PreparedGallery(gallery_normalized) if gallery_normalized.shape[0] else None
 
     @staticmethod
     def pack(vals, idx, Q, k, device):
@@ -48,7 +54,8 @@ class _HipOps:
 
 
 class ShardedGallery:
-    def __init__(self, local_rows: torch.Tensor, group=None, ops=None, labels: torch.Tensor | None = None):
+    def __init__(self, local_rows: torch.Tensor, group=None, ops=None, labels: torch.Tensor | None = None,
+                 prepared: bool = False):
         self.ops = ops or _HipOps
         self.group = group
         dist = torch.distributed
@@ -60,6 +67,8 @@ class ShardedGallery:
         self.device = local_rows.device
         self.local = self.ops.normalize(local_rows.float().contiguous()) if local_rows.shape[0] else local_rows.float()
         self.labels = labels
+        # prepared=True: the shard is also kept as the cosine GEMM's bf16 planes (+6 B per element; same results bit for bit)
+        self.prepared = self.ops.prepare(self.local) if (prepared and hasattr(self.ops, "prepare")) else None
         if self.world > 1:
             n = torch.tensor([local_rows.shape[0]], dtype=torch.int64, device=self.device)
             allc = torch.empty(self.world, dtype=torch.int64, device=self.device)
@@ -80,12 +89,17 @@ class ShardedGallery:
     def offset(self) -> int:
         return self.offsets[self.rank]
 
+    def _local_topk(self, queries, k):
+        if self.prepared is not None:
+            return self.ops.local_topk(queries, self.local, k, 0, prepared=self.prepared)
+        return self.ops.local_topk(queries, self.local, k, 0)
+
     def _local_candidates(self, queries, k):
         """(Q, k, 2) int32: [..., 0] = the f32 score's bits, [..., 1] = LOCAL row index; a short (or empty) shard pads to
         exactly k slots with {-inf, -1} (one library kernel: mi355_pack_candidates)."""
         Q = queries.shape[0]
         kk = min(k, self.local.shape[0])
-        v, i = self.ops.local_topk(queries, self.local, kk, 0) if kk > 0 else (None, None)
+        v, i = self._local_topk(queries, kk) if kk > 0 else (None, None)
         return self.ops.pack(v, i, Q, k, self.device)
 
     def search(self, queries_local: torch.Tensor, k: int):
@@ -97,7 +111,7 @@ class ShardedGallery:
             raise MI355Error(f"selected index k out of range: k={k}, gallery rows={self.total_rows}")
         q = queries_local.float().contiguous()
         if self.world == 1:
-            return self.ops.local_topk(q, self.local, k, 0)
+            return self._local_topk(q, k)
         dist = torch.distributed
         Ql = q.shape[0]
         allq = torch.empty((self.world * Ql, self.dim), dtype=torch.float32, device=self.device)

@@ -69,6 +69,17 @@ int mi355_rank_topk(const float* queries, int64_t Q, const float* gallery, int64
                     void* stream);
 
 /* Scores only: out[Q][G] fp32 cosine matrix (same kernel as above without the selection). */
+/* Prepared gallery for RESIDENT galleries (the reference re-reads and re-normalises its gallery for every query,
+ * train/train.py:250; here it is normalised once when rows are added, and - optionally - split once into the three bf16 planes
+ * the cosine GEMM multiplies, stored in the GEMM's fragment order: 6 B per element, mi355_gallery_planes_bytes(G, dim) bytes).
+ * mi355_rank_topk_prepared then does no per-call work on the gallery side at all; k <= 8 and Q > 4 (other shapes: mi355_rank_topk
+ * with the fp32 rows).  Values and indices are bit-identical to mi355_rank_topk(gallery_is_normalized = 1) on the same rows. */
+size_t mi355_gallery_planes_bytes(int64_t G, int dim);
+int mi355_gallery_prepare(const float* gallery_normalized, int64_t G, int dim, void* planes, size_t planes_bytes, void* stream);
+int mi355_rank_topk_prepared(const float* queries, int64_t Q, const void* gallery_planes, int64_t G, int dim, int k, float eps,
+                             int64_t idx_offset, float* out_val, int64_t* out_idx, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
 int mi355_cosine_scores(const float* queries, int64_t Q, const float* gallery, int64_t G, int dim,
                         int gallery_is_normalized, float eps, float* out, void* workspace,
                         size_t workspace_bytes, void* stream);

@@ -388,3 +388,38 @@ def test_few_queries_with_rows_too_long_for_the_gemv():
     np.testing.assert_allclose(s, want, rtol=0, atol=1e-6)
     v, i = M.cosine_topk(dev(q), dev(g), 3)
     np.testing.assert_array_equal(i.cpu().numpy(), np.argsort(-want, axis=1)[:, :3])
+
+
+@pytest.mark.parametrize("Q,G,D,k", [(256, 100000, 1536, 3), (64, 10000, 1536, 3), (16, 1000, 1536, 1), (300, 5000, 200, 8), (7, 333, 72, 2)])
+def test_prepared_gallery_is_bit_identical_to_the_fp32_rows(Q, G, D, k):
+    """mi355_gallery_prepare holds a resident gallery as the cosine GEMM's three bf16 planes (6 B per element, fragment order);
+    mi355_rank_topk_prepared then multiplies them without any per-call work on the gallery side.  The planes are the same values
+    the split loop derives in registers (split3 of the same normalised fp32 rows) and the six products are accumulated in
+    the same order: values AND indices must be identical bits - at the metric's shape (two query blocks, whole rounds +
+    64-row tail launch), for a single 64-query tile, ragged D / G / Q and the 3-stage MT = 1 ring."""
+    import imageretrievalresearch_amd as M
+    from imageretrievalresearch_amd import synth
+    q = M.synth_fill(Q * D, 13, synth.NORMAL, DEV).view(Q, D)
+    g = M.l2_normalize_rows(M.synth_fill(G * D, 5, synth.NORMAL, DEV).view(G, D))
+    wv, wi = M.cosine_topk(q, g, k, gallery_is_normalized=True, idx_offset=11)
+    p = M.PreparedGallery(g)
+    v, i = p.search(q, k, idx_offset=11)
+    assert torch.equal(v, wv) and torch.equal(i, wi)
+    gal = M.Gallery(D, DEV)
+    gal.add(g)                                  # (already unit rows: normalising again leaves them within 1 ulp, so compare to itself)
+    a = gal.search(q, k)
+    gal.prepare()
+    b = gal.search(q, k)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_prepared_gallery_rejects_what_it_does_not_cover():
+    import imageretrievalresearch_amd as M
+    from imageretrievalresearch_amd import synth
+    g = M.l2_normalize_rows(M.synth_fill(500 * 64, 5, synth.NORMAL, DEV).view(500, 64))
+    p = M.PreparedGallery(g)
+    q = M.synth_fill(8 * 64, 3, synth.NORMAL, DEV).view(8, 64)
+    with pytest.raises(M.MI355Error):
+        p.search(q, 150)                        # k > 8: the score-slab path needs the fp32 rows
+    with pytest.raises(M.MI355Error):
+        p.search(q[:2], 3)                      # Q <= 4: the GEMV streams the fp32 rows

@@ -17,4 +17,12 @@ for Q, G in cases:
     for _ in range(n): M.cosine_topk(q, g, 3, gallery_is_normalized=True)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
     print(f"Q={Q} G={G}: {dt*1e3:.3f} ms  {Q/dt:.0f} q/s  {2.0*Q*G*1536/dt/1e12:.1f} TFLOP/s  {4.0*G*1536/dt/1e9:.0f} GB/s gallery stream")
+    if M.PreparedGallery.supports(Q, 3) and not os.environ.get("NO_PREPARED"):
+        p = M.PreparedGallery(g)
+        for _ in range(25): p.search(q, 3)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(n): p.search(q, 3)
+        torch.cuda.synchronize(); dp = (time.perf_counter() - t) / n
+        print(f"Q={Q} G={G} prepared gallery (bf16 planes, 6 B/element): {dp*1e3:.3f} ms  {Q/dp:.0f} q/s  {2.0*Q*G*1536/dp/1e12:.1f} TFLOP/s  {6.0*G*1536/dp/1e9:.0f} GB/s plane stream")
+        del p
     del g
