@@ -401,6 +401,50 @@ __global__ __launch_bounds__(MB_THREADS) void k_mbconv_block(const BlockArgs a) 
         tick(2);
         asm volatile("" ::: "memory");   // (the next slab rewrites only this wave's own E channels: no barrier)
     }
+    // ---- SE FC1 weights of this wave's first group of four hidden units: requested BEFORE the wait for the slowest wave (they
+    // need nothing from the other waves), so the L2 round trip runs under that wait instead of behind it.  Groups of four units
+    // are rotated by image (L2 spreading); a unit keeps its slot q = unit % 4 in every image, so that the code that produces it -
+    // and with it the last bit of its sum - does not depend on the batch position.
+    constexpr int C8MAX = 5;                              // ceil(mid / 8 / 64) <= 5  (mid <= 2560, checked on the host)
+    const int ngroups = (abl & 4) ? 0 : (a.rd + 3) >> 2;
+    auto fc1_load = [&](int gi, u32x4 (&w)[C8MAX][4], float (&b1v)[4]) {
+        const int j0 = ((gi + rb1) % max(ngroups, 1)) * 4;
+#pragma unroll
+        for (int it = 0; it < C8MAX; ++it) {
+            const int c8 = min(lane + it * 64, (a.mid >> 3) - 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                w[it][q] = *reinterpret_cast<const u32x4*>(a.W1 + (min(j0 + q, a.rd - 1) * a.mid + c8 * 8));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b1v[q] = a.b1[min(j0 + q, a.rd - 1)];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto fc1_compute = [&](int gi, const u32x4 (&w)[C8MAX][4], const float (&b1v)[4]) {
+        const int j0 = ((gi + rb1) % max(ngroups, 1)) * 4;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < C8MAX; ++it) {
+            const int c8 = lane + it * 64;
+            if (c8 * 8 < a.mid) {
+                const f32x4 p0 = *reinterpret_cast<const f32x4*>(&pool[c8 * 8]);
+                const f32x4 p1 = *reinterpret_cast<const f32x4*>(&pool[c8 * 8 + 4]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    s[q] += mb_lo(w[it][q].x) * p0.x; s[q] += mb_hi(w[it][q].x) * p0.y; s[q] += mb_lo(w[it][q].y) * p0.z; s[q] += mb_hi(w[it][q].y) * p0.w;
+                    s[q] += mb_lo(w[it][q].z) * p1.x; s[q] += mb_hi(w[it][q].z) * p1.y; s[q] += mb_lo(w[it][q].w) * p1.z; s[q] += mb_hi(w[it][q].w) * p1.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float t = wave_sum(s[q]);
+            if (lane == 0 && j0 + q < a.rd) rvec[j0 + q] = apply_act(t * a.inv_hw + b1v[q], a.se_act);
+        }
+    };
+    u32x4 f1a[C8MAX][4], f1b[C8MAX][4];
+    float f1ba[4], f1bb[4];
+    if (wave < ngroups) fc1_load(wave, f1a, f1ba);
     __syncthreads();      // full fence: the depthwise output (global) is re-read by other waves in the projection
     tick(3);
 
@@ -495,89 +539,69 @@ __global__ __launch_bounds__(MB_THREADS) void k_mbconv_block(const BlockArgs a) 
         };
 
     // ------------------------------------------------------------------ SE gate (bf16 weights, fp32 math)
-    // FC1: a wave per hidden unit, four units per pass; ALL of a pass's weight loads (<= 5 x 4 x 16 B per lane) are requested
-    // before the first multiply, so a pass costs one L2 round trip
-    {
-        constexpr int C8MAX = 5;                              // ceil(mid / 8 / 64) <= 5  (mid <= 2560, checked on the host)
-        // groups of four units are rotated by image (L2 spreading); a unit keeps its slot q = unit % 4 in every image, so
-        // that the code that produces it - and with it the last bit of its sum - does not depend on the batch position
-        const int ngroups = (a.rd + 3) >> 2;
-        for (int gi = wave; gi < ((abl & 4) ? 0 : ngroups); gi += MB_WAVES) {
-            const int j0 = ((gi + rb1) % ngroups) * 4;
-            u32x4 w[C8MAX][4];
-#pragma unroll
-            for (int it = 0; it < C8MAX; ++it) {
-                const int c8 = min(lane + it * 64, (a.mid >> 3) - 1);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    w[it][q] = *reinterpret_cast<const u32x4*>(a.W1 + (min(j0 + q, a.rd - 1) * a.mid + c8 * 8));
-            }
-            float b1v[4];                                      // requested with the weights: as a load behind the reduction it was
-#pragma unroll                                             // one more exposed L2 round trip per pass
-            for (int q = 0; q < 4; ++q) b1v[q] = a.b1[min(j0 + q, a.rd - 1)];
-            __builtin_amdgcn_sched_barrier(0);
-            float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int it = 0; it < C8MAX; ++it) {
-                const int c8 = lane + it * 64;
-                if (c8 * 8 < a.mid) {
-                    const f32x4 p0 = *reinterpret_cast<const f32x4*>(&pool[c8 * 8]);
-                    const f32x4 p1 = *reinterpret_cast<const f32x4*>(&pool[c8 * 8 + 4]);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        s[q] += mb_lo(w[it][q].x) * p0.x; s[q] += mb_hi(w[it][q].x) * p0.y; s[q] += mb_lo(w[it][q].y) * p0.z; s[q] += mb_hi(w[it][q].y) * p0.w;
-                        s[q] += mb_lo(w[it][q].z) * p1.x; s[q] += mb_hi(w[it][q].z) * p1.y; s[q] += mb_lo(w[it][q].w) * p1.z; s[q] += mb_hi(w[it][q].w) * p1.w;
-                    }
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float t = wave_sum(s[q]);
-                if (lane == 0 && j0 + q < a.rd) rvec[j0 + q] = apply_act(t * a.inv_hw + b1v[q], a.se_act);
-            }
+    // FC1: a wave per group of four hidden units; all weight loads of a group (<= 5 x 4 x 16 B per lane) are in flight one group
+    // ahead of the multiplies (two register sets; the first group was requested in front of the barrier above)
+    for (int gi = wave; gi < ngroups; gi += 2 * MB_WAVES) {
+        if (gi + MB_WAVES < ngroups) fc1_load(gi + MB_WAVES, f1b, f1bb);
+        fc1_compute(gi, f1a, f1ba);
+        if (gi + MB_WAVES < ngroups) {
+            if (gi + 2 * MB_WAVES < ngroups) fc1_load(gi + 2 * MB_WAVES, f1a, f1ba);
+            fc1_compute(gi + MB_WAVES, f1b, f1bb);
         }
     }
+    // FC2: thread = (8-channel chunk, slice of the hidden units).  Its first batch of weights needs only addresses: requested
+    // in front of the barrier that publishes the hidden vector.
+    const int nch = a.mid >> 3;
+    int JS = MB_THREADS / nch;
+    if (JS > 8) JS = 8;
+    if (JS < 1) JS = 1;
+    constexpr int NBJ = 16;
+    const int f2_ch0 = tid % nch + (tid / nch >= JS ? nch : 0);
+    const bool f2_has = f2_ch0 < nch;                          // (nch <= 320 < 512 threads: at most one chunk per thread)
+    const int f2_ch = (min(f2_ch0, nch - 1) + rb2 * 7) % nch;  // channel chunks rotated by image (L2 spreading)
+    const int f2_js = JS == 1 ? 0 : min(tid / nch, JS - 1);
+    const int f2_rd = (abl & 4) ? 0 : a.rd;
+    auto fc2_load = [&](int jb, u32x4 (&w)[NBJ]) {
+#pragma unroll
+        for (int t = 0; t < NBJ; ++t) w[t] = *reinterpret_cast<const u32x4*>(a.W2 + (min(jb + t * JS, a.rd - 1) * a.mid + f2_ch * 8));
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    u32x4 f2a[NBJ], f2b[NBJ];
+    if (f2_js < f2_rd) fc2_load(f2_js, f2a);
     mb_lds_barrier();
     tick(4);
-    // FC2: thread = (8-channel chunk, slice of the hidden units); partials through LDS, summed in slice order
+    // FC2 (continued): partials through LDS, summed in slice order
     {
-        const int nch = a.mid >> 3;
-        int JS = MB_THREADS / nch;
-        if (JS > 8) JS = 8;
-        if (JS < 1) JS = 1;
         float* part = reinterpret_cast<float*>(R);           // [JS][mid]
         // the gate's bias, requested before anything else of this phase: as a load inside the reduction loop below it waited (vmcnt
         // is in order) for the whole first A chunk of the projection that is requested in between
         float b2v[5];                                        // mid <= 2560 (host check): <= 5 channels per thread
 #pragma unroll
         for (int i = 0; i < 5; ++i) b2v[i] = a.b2[min(tid + i * MB_THREADS, a.mid - 1)];
-        for (int ch0 = tid % nch + (tid / nch >= JS ? nch : 0); ch0 < nch; ch0 += (JS == 1 ? MB_THREADS : nch)) {
-            const int ch = (ch0 + rb2 * 7) % nch;              // channel chunks rotated by image (L2 spreading)
-            const int js = JS == 1 ? 0 : tid / nch;
+        if (f2_has) {
             float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            // batches of NBJ loads, all requested before the first multiply (a `#pragma unroll 12` over the runtime trip count put
-            // every iteration of short loops into the one-at-a-time remainder loop: a dependent L2 round trip per hidden unit);
-            // slots past rd re-read the last row and multiply by zero - the order of the real terms is unchanged
-            constexpr int NBJ = 16;
-            for (int jb = js; jb < ((abl & 4) ? 0 : a.rd); jb += JS * NBJ) {
-                u32x4 w[NBJ];
-                float r[NBJ];
+            // batches of NBJ loads, all in flight a batch ahead of their multiplies (two register sets); slots past rd re-read the
+            // last row and multiply by zero - the order of the real terms is unchanged
+            auto fc2_mac = [&](int jb, const u32x4 (&w)[NBJ]) {
 #pragma unroll
                 for (int t = 0; t < NBJ; ++t) {
                     const int j = jb + t * JS;
-                    w[t] = *reinterpret_cast<const u32x4*>(a.W2 + (min(j, a.rd - 1) * a.mid + ch * 8));
-                    r[t] = j < a.rd ? rvec[j] : 0.f;
+                    const float r = j < a.rd ? rvec[j] : 0.f;
+                    s[0] += mb_lo(w[t].x) * r; s[1] += mb_hi(w[t].x) * r; s[2] += mb_lo(w[t].y) * r; s[3] += mb_hi(w[t].y) * r;
+                    s[4] += mb_lo(w[t].z) * r; s[5] += mb_hi(w[t].z) * r; s[6] += mb_lo(w[t].w) * r; s[7] += mb_hi(w[t].w) * r;
                 }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < NBJ; ++t) {
-                    s[0] += mb_lo(w[t].x) * r[t]; s[1] += mb_hi(w[t].x) * r[t]; s[2] += mb_lo(w[t].y) * r[t]; s[3] += mb_hi(w[t].y) * r[t];
-                    s[4] += mb_lo(w[t].z) * r[t]; s[5] += mb_hi(w[t].z) * r[t]; s[6] += mb_lo(w[t].w) * r[t]; s[7] += mb_hi(w[t].w) * r[t];
+            };
+            const int step = JS * NBJ;
+            for (int jb = f2_js; jb < f2_rd; jb += 2 * step) {
+                if (jb + step < f2_rd) fc2_load(jb + step, f2b);
+                fc2_mac(jb, f2a);
+                if (jb + step < f2_rd) {
+                    if (jb + 2 * step < f2_rd) fc2_load(jb + 2 * step, f2a);
+                    fc2_mac(jb + step, f2b);
                 }
             }
-            *reinterpret_cast<f32x4*>(&part[js * a.mid + ch * 8]) = (f32x4){s[0], s[1], s[2], s[3]};
-            *reinterpret_cast<f32x4*>(&part[js * a.mid + ch * 8 + 4]) = (f32x4){s[4], s[5], s[6], s[7]};
-            if (JS > 1) break;
+            *reinterpret_cast<f32x4*>(&part[f2_js * a.mid + f2_ch * 8]) = (f32x4){s[0], s[1], s[2], s[3]};
+            *reinterpret_cast<f32x4*>(&part[f2_js * a.mid + f2_ch * 8 + 4]) = (f32x4){s[4], s[5], s[6], s[7]};
         }
         mb_lds_barrier();
         // the first projection operands are requested here: they travel while the gate is reduced (and A is staged / zeroed)

@@ -795,8 +795,9 @@ int mi355_model_forward_u8(mi355_model_t m, const unsigned char* images, int B, 
     MI355_REQUIRE(B >= 1 && h >= 1 && w >= 1 && h <= 16384 && w <= 16384, "forward_u8: bad image size %dx%d", h, w);
     MI355_REQUIRE(fill >= 0 && fill <= 255, "forward_u8: fill must be a byte value");
     for (int c = 0; c < 3; ++c) MI355_REQUIRE(stdv[c] != 0.f, "forward_u8: std[%d] is zero", c);
-    MI355_REQUIRE(!m->def.ops.empty() && m->def.ops[0].kind == OP_STEM,
-                  "forward_u8: %s has no 3x3 stem to fuse the pre-processing into", m->def.arch.c_str());
+    MI355_REQUIRE(!m->def.ops.empty() && (m->def.ops[0].kind == OP_STEM || m->def.ops[0].kind == OP_PATCH_EMBED),
+                  "forward_u8: %s has no stem / patch embedding to fuse the pre-processing into", m->def.arch.c_str());
+    MI355_REQUIRE(m->def.ops[0].kind == OP_STEM || !conv_input_w, "forward_u8: conv_input belongs to the convolutional backbones");
     U8Source u{};
     u.img = images; u.h = h; u.w = w; u.fill = fill; u.conv_w = conv_input_w;
     for (int c = 0; c < 3; ++c) { u.mean[c] = mean[c]; u.stdv[c] = stdv[c]; }

@@ -64,7 +64,8 @@ struct mi355_model {
                                 // classes where it was measured faster than the unfused pair (see can_fuse in model.hip)
     bool fuse = true;           // fused expand+depthwise for whole-image tiles (option "fuse")
     int fuse_block = 1;         // whole MBConv block in one kernel for the 14x14 / 7x7 stages (option "fuse_block"; 0 = off)
-    int fuse_block_min_batch = 192; // ... only when the caller's whole batch has at least this many images: one workgroup per image needs ~a CU per image
+    int fuse_block_min_batch = 96;  // ... only when the caller's whole batch has at least this many images (one workgroup per image: measured on
+                                    // EfficientNet-B3a in round 3, tools/bench_thresholds.py: B = 64 2.20 vs 1.98 ms unfused, B = 96 2.50 vs 2.66, B = 128 2.65 vs 2.86)
                                     // (measured B=128: 3.16 ms with, 3.01 without; B=256: 4.38 with, 4.7 without; B<=32: +0.4 ms)
     int block_variant = 0;      // tuning (option "block_variant"): see BlockArgs::variant
     int block_norot = 0;        // diagnosis (option "block_norot"): see BlockArgs::norot

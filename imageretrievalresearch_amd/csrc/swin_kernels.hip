@@ -8,6 +8,8 @@
 // O^T = V^T P^T (k permuted the same way on the V^T side).  Only V goes through LDS (transposed, 4.6 KB / wave).
 #include "model_exec.h"
 
+#include <algorithm>
+
 namespace mi355 {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -45,7 +47,16 @@ __device__ __forceinline__ float group_sum(float v) {
 constexpr int PE_PPT = 7;          // patches per thread
 constexpr int PE_PG = 16;          // patch groups per block (x 16 channel groups = 256 threads)
 constexpr int PE_P = PE_PPT * PE_PG;   // 112 patches per block = 2 patch rows at gw = 56
-__global__ __launch_bounds__(256) void k_patch_embed(const float* __restrict__ x, const float* __restrict__ w,
+// U8: the input is a batch of decoded uint8 images [B][h][w][3] and the reference's inference transform - SquarePad(fill) ->
+// ToTensor -> Normalize(mean, std), inference/inference.py:48-52 - is applied while the patch rows are loaded (same fp32
+// operation order as k_square_pad_normalize: bit-identical to that kernel followed by the fp32 form; no fp32 NCHW batch in HBM).
+struct PatchU8Args {
+    const unsigned char* img;   // [B][h][w][3]
+    int h, w, hp, vp, fill;     // hp / vp = left / top padding of the 224 x 224 square
+    float mean[3], stdv[3];
+};
+template <bool U8>
+__global__ __launch_bounds__(256) void k_patch_embed(const float* __restrict__ x, const PatchU8Args u, const float* __restrict__ w,
                                                      const float* __restrict__ bias, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16_t* __restrict__ out, int H,
                                                      int W, int gw, int L, float eps) {
@@ -59,8 +70,23 @@ __global__ __launch_bounds__(256) void k_patch_embed(const float* __restrict__ x
         const int pyl = r / 12, cd = r - pyl * 12, ci = cd >> 2, dy = cd & 3;
         const int py = py0 + pyl;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (py * gw + px < L)
-            v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * 3 + ci) * H + 4 * py + dy) * W + 4 * px);
+        if (py * gw + px < L) {
+            if constexpr (U8) {
+                const unsigned char* ib = u.img + (size_t)b * u.h * u.w * 3;
+                const int iy = 4 * py + dy - u.vp;
+                float e[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ix = 4 * px + q - u.hp;
+                    int pv = u.fill;
+                    if (iy >= 0 && iy < u.h && ix >= 0 && ix < u.w) pv = ib[((size_t)iy * u.w + ix) * 3 + ci];
+                    e[q] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)pv, 255.0f), u.mean[ci]), u.stdv[ci]);
+                }
+                v = (f32x4){e[0], e[1], e[2], e[3]};
+            } else {
+                v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * 3 + ci) * H + 4 * py + dy) * W + 4 * px);
+            }
+        }
         *reinterpret_cast<f32x4*>(&xin[pyl * gw + px][ci * 16 + dy * 4]) = v;
     }
     __syncthreads();
@@ -456,9 +482,20 @@ int swin_exec(const ModelDef& def, const Op& op, ExecCtx& cx) {
             MI355_REQUIRE(cx.H == 224 && cx.W == 224, "swin needs 224x224 input");
             const int gw = cx.W / 4, L = gw * (cx.H / 4);
             MI355_REQUIRE(2 * gw == PE_P, "patch_embed: kernel is laid out for 56 patches per row");
-            hipLaunchKernelGGL(k_patch_embed, dim3(cdiv(L, PE_P), cx.nb), dim3(256), 0, cx.st, cx.x, (const float*)cx.w(op.w_off),
-                               (const float*)cx.w(op.b_off), (const float*)cx.w(op.w2_off), (const float*)cx.w(op.b2_off),
-                               (bf16_t*)cx.slot_ptr(op.out), cx.H, cx.W, gw, L, op.ln_eps);
+            PatchU8Args u{};
+            if (cx.x_u8) {            // uint8 images: SquarePad + ToTensor + Normalize fused into the patch loads (mi355_model_forward_u8)
+                MI355_REQUIRE(!cx.conv_w, "swin: the conv_input pre-stem belongs to the convolutional backbones");
+                MI355_REQUIRE(std::max(cx.img_h, cx.img_w) == 224, "swin needs images whose longer side is 224 (got %dx%d)", cx.img_h, cx.img_w);
+                u.img = cx.x_u8; u.h = cx.img_h; u.w = cx.img_w; u.hp = (224 - cx.img_w) / 2; u.vp = (224 - cx.img_h) / 2; u.fill = cx.fill;
+                for (int c = 0; c < 3; ++c) { u.mean[c] = cx.mean[c]; u.stdv[c] = cx.stdv[c]; }
+                hipLaunchKernelGGL(k_patch_embed<true>, dim3(cdiv(L, PE_P), cx.nb), dim3(256), 0, cx.st, (const float*)nullptr, u,
+                                   (const float*)cx.w(op.w_off), (const float*)cx.w(op.b_off), (const float*)cx.w(op.w2_off),
+                                   (const float*)cx.w(op.b2_off), (bf16_t*)cx.slot_ptr(op.out), cx.H, cx.W, gw, L, op.ln_eps);
+            } else {
+                hipLaunchKernelGGL(k_patch_embed<false>, dim3(cdiv(L, PE_P), cx.nb), dim3(256), 0, cx.st, cx.x, u, (const float*)cx.w(op.w_off),
+                                   (const float*)cx.w(op.b_off), (const float*)cx.w(op.w2_off), (const float*)cx.w(op.b2_off),
+                                   (bf16_t*)cx.slot_ptr(op.out), cx.H, cx.W, gw, L, op.ln_eps);
+            }
             MI355_LAUNCH_CHECK();
             return OK;
         }

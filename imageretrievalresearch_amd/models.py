@@ -463,13 +463,14 @@ class MI355Model(nn.Module):
         on the GPU (one size per batch) -> SquarePad(fill) -> ToTensor -> Normalize(mean, std) (inference/inference.py:48-52)
         -> ``conv_input`` (the ``Sequential(Conv2d(3,3,3,1,1,bias=False), SiLU)`` of inference/inference.py:103-105, or
         None) -> stem ... -> ``forward`` (or ``forward_features`` with ``features=True``).  No fp32 NCHW batch is ever
-        written; bit-identical to ``preprocess.square_pad_normalize`` + ``conv_input`` + ``forward``."""
+        written; bit-identical to ``preprocess.square_pad_normalize`` + ``conv_input`` + ``forward``.  Swin fuses the
+        transform into its 4x4 patch embedding the same way (images whose longer side is 224, no conv_input)."""
         self._refuse_training()
         require_cuda(images, "images")
         if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[3] != 3:
             raise MI355Error(f"forward_uint8 expects uint8 (B, h, w, 3), got {images.dtype} {tuple(images.shape)}")
-        if self.family == "swin":
-            raise MI355Error("forward_uint8: swin has no 3x3 stem to fuse the pre-processing into")
+        if self.family == "swin" and conv_input is not None:
+            raise MI355Error("forward_uint8: conv_input belongs to the convolutional backbones (swin fuses the transform into its patch embedding)")
         images = images.contiguous()
         self._ensure_packed(images.device)
         B, h, w, _ = images.shape
@@ -481,7 +482,9 @@ class MI355Model(nn.Module):
                 raise MI355Error("conv_input must be Sequential(Conv2d(3, 3, 3, 1, 1, bias=False), SiLU)")
             cw = conv.weight.detach().to(images.device, torch.float32).contiguous()
         D = self.num_features
-        if features:
+        if features and self.family == "swin":
+            out = torch.empty((B, D), dtype=torch.float32, device=images.device)      # timm's swin forward_features is pooled
+        elif features:
             out = torch.empty((B, D, (S + 31) // 32, (S + 31) // 32), dtype=torch.float32, device=images.device)
         else:
             out = torch.empty((B, self.num_classes if self.num_classes > 0 else D), dtype=torch.float32, device=images.device)

@@ -117,9 +117,9 @@ def test_deterministic_and_batch_invariant(setup):
     assert torch.equal(a, d)
 
 
-@pytest.mark.parametrize("B,mb", [(256, 100), (200, 150), (90, 30)])
+@pytest.mark.parametrize("B,mb", [(256, 100), (120, 70), (90, 30)])
 def test_chunking_does_not_change_the_bits(setup, B, mb):
-    """the whole-block kernel (chosen from 192 images up) and the split-K projections (chosen up to 16 384 rows, i.e.
+    """the whole-block kernel (chosen from 96 images up) and the split-K projections (chosen up to 16 384 rows, i.e.
     83 images at 14x14) round differently from their alternatives, and both used to be chosen by the CHUNK a forward is cut
     into - a microbatch remainder or a lane embedded differently from the same image in the unchunked batch.  The choice now
     follows the caller's whole batch: microbatches that straddle either threshold, and two concurrent lanes, give the same bits."""
@@ -263,7 +263,7 @@ def test_block_kernel_agrees_with_the_unfused_chain(setup):
     x = torch.from_numpy(images(17, 3)).to(DEV)
     names = ["blocks.3.0", "blocks.3.1", "blocks.4.0", "blocks.5.0", "blocks.6.1", "head"]
     taps = {}
-    model.set_option("fuse_block_min_batch", 1)      # the default only picks the block kernel for >= 192 images
+    model.set_option("fuse_block_min_batch", 1)      # the default only picks the block kernel for >= 96 images
     for opt in (0, 1):
         model.set_option("fuse_block", opt)
         model.enable_taps(True)
@@ -278,7 +278,7 @@ def test_block_kernel_agrees_with_the_unfused_chain(setup):
         assert rel(taps[1][n], taps[0][n]) < 1.2e-2, n
     xx = x[:1].repeat(5, 1, 1, 1).contiguous()                            # same image at five batch positions
     out = model.forward_features(xx)
-    model.set_option("fuse_block_min_batch", 192)
+    model.set_option("fuse_block_min_batch", 96)
     for i in range(1, 5):
         assert torch.equal(out[0], out[i]), i
 

@@ -28,7 +28,7 @@ def taps(B, fuse_block, variant):
     out = model(x)
     t = {n: model.read_tap(n).float().cpu() for n in names}
     model.enable_taps(False)
-    model.set_option("fuse_block_min_batch", 192)
+    model.set_option("fuse_block_min_batch", 96)
     return t, out.float().cpu()
 
 
