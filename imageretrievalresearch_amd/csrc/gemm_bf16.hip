@@ -1074,6 +1074,105 @@ static int launch_nt(const GemmArgs& a, int nt, hipStream_t st) {
     }
 }
 
+// =====================================================================================
+// Head 1x1 conv + bias + activation + GLOBAL AVERAGE POOL in one kernel (get_fm, train/train.py:84-103, is the
+// epilogue of conv_head / features.16 whenever the caller wants the pooled embedding): one workgroup = one image x 128 output
+// channels, so a tile never spans two images and the pooled value of a channel is complete inside the workgroup.  The head
+// tensor (B x 49 x 1536 bf16: 38.5 MB written and re-read at B = 256) and the k_gap launch (25 us) disappear.
+// Same arithmetic as the two-kernel path, bit for bit: fp32 MFMA accumulation over ascending k-steps from zero, bias added
+// last, activation, ONE bf16 rounding per element, then the sequential fp32 sum over the pixels in ascending order and one
+// multiply by 1 / HW (k_gap's order).  Operands come straight from L2 into MFMA fragments (K <= 512, HW <= 64: 12 k-steps).
+// =====================================================================================
+template <int ACT>
+__global__ __launch_bounds__(256) void k_head_gap(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
+                                                  const float* __restrict__ bias, float* __restrict__ pooled,
+                                                  bf16_t* __restrict__ pooled_bf16, int ldp, int HW, int N, int K) {
+    constexpr int TLD = 132;
+    __shared__ __attribute__((aligned(16))) float T[64 * TLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int b = blockIdx.y, n0 = blockIdx.x * 128;
+    const int Npad = (N + 15) & ~15;
+    const bf16_t* Ab = A + (size_t)b * HW * lda;
+    const bf16_t* arow[2];
+    const bf16_t* wrow[4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) arow[mi] = Ab + (size_t)min(wm * 32 + mi * 16 + fr, HW - 1) * lda;   // rows past the image: clamped, never summed
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) wrow[ni] = W + (size_t)min(n0 + wn * 64 + ni * 16 + fr, Npad - 1) * ldw;
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nks = (K + 31) >> 5;
+    u32x4 af[2][2], wf[2][4];
+    // k >= lda (the weight matrix is zero there): re-read the row's last 16 bytes instead of running past it
+    auto load = [&](int s, int ks) {
+        const int ka = min(ks * 32 + fq * 8, lda - 8), kw = ks * 32 + fq * 8;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) af[s][mi] = *reinterpret_cast<const u32x4*>(arow[mi] + ka);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) wf[s][ni] = *reinterpret_cast<const u32x4*>(wrow[ni] + kw);
+    };
+    load(0, 0);
+    for (int ks = 0; ks < nks; ks += 2) {
+        if (ks + 1 < nks) load(1, ks + 1);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wf[0][ni]), *reinterpret_cast<bf16x8*>(&af[0][mi]), acc[ni][mi], 0, 0, 0);
+        if (ks + 1 < nks) {
+            if (ks + 2 < nks) load(0, ks + 2);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wf[1][ni]), *reinterpret_cast<bf16x8*>(&af[1][mi]), acc[ni][mi], 0, 0, 0);
+        }
+    }
+    // bias + activation + the bf16 rounding the head tensor would have had, into the LDS tile [pixel][channel]
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int nl = wn * 64 + ni * 16 + fq * 4;
+        f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+        if (n0 + nl < Npad) bb = *reinterpret_cast<const f32x4*>(bias + n0 + nl);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int ml = wm * 32 + mi * 16 + fr;
+            f32x4 v;
+            v.x = bf2f(f2bf(act_c<ACT>(acc[ni][mi].x + bb.x))); v.y = bf2f(f2bf(act_c<ACT>(acc[ni][mi].y + bb.y)));
+            v.z = bf2f(f2bf(act_c<ACT>(acc[ni][mi].z + bb.z))); v.w = bf2f(f2bf(act_c<ACT>(acc[ni][mi].w + bb.w)));
+            *reinterpret_cast<f32x4*>(&T[ml * TLD + nl]) = v;
+        }
+    }
+    __syncthreads();
+    if (tid < 128 && n0 + tid < N) {
+        float s = 0.f;
+        for (int i = 0; i < HW; ++i) s += T[i * TLD + tid];
+        s *= 1.0f / (float)HW;
+        pooled[(size_t)b * ldp + n0 + tid] = s;
+        if (pooled_bf16) pooled_bf16[(size_t)b * ldp + n0 + tid] = f2bf(s);
+    }
+}
+
+bool head_gap_supported(int HW, int N, int K, int lda, int ldw, int act) {
+    return HW >= 1 && HW <= 64 && K >= 32 && K <= 512 && lda % 8 == 0 && lda >= 8 && ldw % 32 == 0 && ldw >= ((K + 31) & ~31) && N % 8 == 0 &&
+           (act == ACT_SILU || act == ACT_NONE);
+}
+
+int launch_head_gap(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, float* pooled, bf16_t* pooled_bf16,
+                    int ldp, int B, int HW, int N, int K, int act, hipStream_t st) {
+    MI355_REQUIRE(head_gap_supported(HW, N, K, lda, ldw, act), "head_gap: unsupported shape HW=%d N=%d K=%d", HW, N, K);
+    const dim3 grid((unsigned)cdiv(N, 128), (unsigned)B);
+    if (act == ACT_SILU) hipLaunchKernelGGL(k_head_gap<ACT_SILU>, grid, dim3(256), 0, st, A, lda, W, ldw, bias, pooled, pooled_bf16, ldp, HW, N, K);
+    else hipLaunchKernelGGL(k_head_gap<ACT_NONE>, grid, dim3(256), 0, st, A, lda, W, ldw, bias, pooled, pooled_bf16, ldp, HW, N, K);
+    MI355_LAUNCH_CHECK();
+    return OK;
+}
+
 int launch_gemm_bf16(const GemmArgs& a, hipStream_t st) {
     MI355_REQUIRE(a.M >= 1 && a.N >= 1 && a.K >= 1, "gemm: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
     MI355_REQUIRE(a.K % 8 == 0 && a.lda % 8 == 0 && a.ldw % 32 == 0, "gemm: K=%d lda=%d ldw=%d alignment", a.K, a.lda,

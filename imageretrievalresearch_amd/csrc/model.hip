@@ -584,10 +584,33 @@ static int forward_impl(mi355_model* m, const float* x, int B, int H, int W, flo
             cx.img_h = u8->h; cx.img_w = u8->w; cx.fill = u8->fill; cx.conv_w = u8->conv_w;
             for (int c = 0; c < 3; ++c) { cx.mean[c] = u8->mean[c]; cx.stdv[c] = u8->stdv[c]; }
         }
-        if (int e = run_backbone(cx)) return e;
+        const bool want_logits = !features_only && d.num_classes > 0;
+        // Pooled embedding wanted and the last op is the head 1x1 conv: conv + bias + act + GAP as ONE kernel (k_head_gap: the
+        // head tensor never reaches HBM).  forward_features, taps and per-op profiling need the un-pooled map: two-kernel path.
+        bool head_fused = false, backbone_done = false;
+        if (!features_only && !d.pools_in_features && m->fuse_head_gap && !m->taps && !m->profile && !d.ops.empty()) {
+            const Op& h = d.ops.back();
+            if (h.kind == OP_GEMM && h.out == d.final_slot && h.in != SLOT_NONE && !h.use_gate && h.res == SLOT_NONE && !h.a_relu6 &&
+                h.ln_w_name.empty()) {
+                if (int e = run_backbone(cx, 0, d.ops.size() - 1)) return e;
+                const SlotState& I = m->slots[h.in];
+                const int hwi = I.h * I.w;
+                if (head_gap_supported(hwi, h.cout, h.cin, h.cin, (h.cin + 31) & ~31, h.act)) {
+                    RoctxRange range(roctx_active() ? "embed/head 1x1 + global average pool" : "");
+                    if (int e = launch_head_gap((const bf16_t*)cx.slot_ptr(h.in), h.cin, (const bf16_t*)cx.w(h.w_off), (h.cin + 31) & ~31,
+                                                (const float*)cx.w(h.b_off), (float*)cx.slot_ptr(SLOT_POOLED),
+                                                want_logits ? (bf16_t*)cx.slot_ptr(SLOT_POOLED_BF16) : nullptr, Dp, nb, hwi, h.cout, h.cin,
+                                                h.act, st))
+                        return e;
+                    head_fused = true;
+                } else if (int e = run_backbone(cx, d.ops.size() - 1)) return e;
+                backbone_done = true;
+            }
+        }
+        if (!backbone_done)
+            if (int e = run_backbone(cx)) return e;
         const SlotState& F = m->slots[d.final_slot];
         const int hw = F.h * F.w;
-        const bool want_logits = !features_only && d.num_classes > 0;
         if (d.pools_in_features) {
             // swin: final op wrote pooled fp32 (+bf16) into SLOT_POOLED / SLOT_POOLED_BF16
             float* pooled = (float*)cx.slot_ptr(SLOT_POOLED);
@@ -606,9 +629,10 @@ static int forward_impl(mi355_model* m, const float* x, int B, int H, int W, flo
             const bool need_pool = !features_only || pooled_out;
             if (need_pool) {
                 float* pooled = (float*)cx.slot_ptr(SLOT_POOLED);   // [nb][Dp]
-                if (int e = launch_gap((const bf16_t*)cx.slot_ptr(d.final_slot), pooled,
-                                       want_logits ? (bf16_t*)cx.slot_ptr(SLOT_POOLED_BF16) : nullptr, nb, hw, F.c, st))
-                    return e;
+                if (!head_fused)
+                    if (int e = launch_gap((const bf16_t*)cx.slot_ptr(d.final_slot), pooled,
+                                           want_logits ? (bf16_t*)cx.slot_ptr(SLOT_POOLED_BF16) : nullptr, nb, hw, F.c, st))
+                        return e;
                 if (!features_only && !want_logits)
                     MI355_CHECK_HIP(hipMemcpy2DAsync(out + (size_t)b0 * D, (size_t)D * 4, pooled, (size_t)Dp * 4,
                                                      (size_t)D * 4, nb, hipMemcpyDeviceToDevice, st));
@@ -841,6 +865,7 @@ int mi355_model_set_option(mi355_model_t m, const char* key, int64_t value) {
     else if (k == "block_stamps") m->block_stamps = value != 0;
     else if (k == "block_norot") m->block_norot = (int)value;
     else if (k == "block_variant") m->block_variant = (int)value;
+    else if (k == "fuse_head_gap") m->fuse_head_gap = value != 0;
     else if (k == "roctx") roctx_enable(value != 0);   // process-wide: ranges around every executor op and rank phase
     else if (k == "profile") {
         m->profile = value != 0;

@@ -67,6 +67,7 @@ struct mi355_model {
     int fuse_block_min_batch = 96;  // ... only when the caller's whole batch has at least this many images (one workgroup per image: measured on
                                     // EfficientNet-B3a in round 3, tools/bench_thresholds.py: B = 64 2.20 vs 1.98 ms unfused, B = 96 2.50 vs 2.66, B = 128 2.65 vs 2.86)
                                     // (measured B=128: 3.16 ms with, 3.01 without; B=256: 4.38 with, 4.7 without; B<=32: +0.4 ms)
+    bool fuse_head_gap = true;  // option "fuse_head_gap": head 1x1 conv + GAP as one kernel when the pooled embedding is all the caller wants
     int block_variant = 0;      // tuning (option "block_variant"): see BlockArgs::variant
     int block_norot = 0;        // diagnosis (option "block_norot"): see BlockArgs::norot
     bool block_stamps = false;  // option "block_stamps": record per-phase cycle counts of the block kernel

@@ -126,6 +126,10 @@ int launch_se(const float* pool_partial, int nblk, float inv_hw, const float* w1
 
 // Global average pool of NHWC bf16 -> pooled fp32 [B][C] (+ optional bf16 copy for the classifier GEMM).
 int launch_gap(const bf16_t* in, float* pooled, bf16_t* pooled_bf16, int B, int HW, int C, hipStream_t st);
+// head 1x1 conv + bias + act + global average pool in one kernel (gemm_bf16.hip); pooled / pooled_bf16: [B][ldp]
+bool head_gap_supported(int HW, int N, int K, int lda, int ldw, int act);
+int launch_head_gap(const bf16_t* A, int lda, const bf16_t* W, int ldw, const float* bias, float* pooled, bf16_t* pooled_bf16,
+                    int ldp, int B, int HW, int N, int K, int act, hipStream_t st);
 
 // ClassifierHead on an un-pooled NCHW fp32 map: pooled_out (optional) [B][C] fp32 = mean over HW; out (when w != null) [B][N]
 // = Linear(bf16(pooled); bf16(w) [N][C], bias [N] or null) with fp32 accumulation.

@@ -382,3 +382,22 @@ def test_roctx_ranges_do_not_change_results(setup):
     finally:
         model.set_option("roctx", 0)
     assert torch.equal(got, want) and torch.equal(v, wv) and torch.equal(i, wi)
+
+
+@pytest.mark.parametrize("name", ["efficientnet_b3a", "rexnet_150", "rexnet_200"])
+def test_head_conv_with_the_pool_in_its_epilogue_is_bit_identical(name):
+    """a6 (get_fm, train/train.py:84-103): when the caller wants the pooled embedding, conv_head / features.16 + bias + SiLU + the
+    global average pool run as ONE kernel per (image, 128 channels) - a tile never spans two images, and the sum over the 49
+    pixels keeps k_gap's sequential order - so embeddings AND logits must be the very bits of the conv -> k_gap path."""
+    model = M.create_model(name, num_classes=1000, seed=9).to(DEV).eval()
+    x = torch.from_numpy(images(43, 5)).to(DEV)
+    model.set_option("fuse_head_gap", 0)
+    emb0, log0 = model.embed(x)
+    out0 = model(x)
+    model.set_option("fuse_head_gap", 1)
+    emb1, log1 = model.embed(x)
+    out1 = model(x)
+    assert torch.equal(emb0, emb1) and torch.equal(log0, log1) and torch.equal(out0, out1)
+    # the un-pooled map is still what forward_features returns, and pooling it by hand gives the same embedding
+    fm = model.forward_features(x)
+    assert torch.equal(M.models.pool_linear(fm), emb1)
