@@ -14,7 +14,7 @@ ROOFLINE = ["bound", "achieved", "peak", "unit", "frac", "traffic"]
 CPU = ["value", "unit", "cores", "kind", "sample"]
 
 
-@pytest.mark.parametrize("name", ["r01_bench_n1.json", "r02_bench_n1.json"])
+@pytest.mark.parametrize("name", ["r01_bench_n1.json", "r02_bench_n1.json", "r03_bench_n1.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     line = open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1]
     d = json.loads(line)

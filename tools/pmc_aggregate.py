@@ -17,13 +17,13 @@ import glob
 import json
 import os
 
-OP_KERNELS = ("k_stem", "k_gemm_bf16", "k_gemm_big", "k_gemm_stream", "k_gemm_splitk", "k_proj_lds", "k_dwconv", "k_dw_tiled", "k_dw3_", "k_se", "k_fused",
+OP_KERNELS = ("k_stem", "k_gemm_bf16", "k_gemm_big", "k_head_gap", "k_gemm_stream", "k_gemm_splitk", "k_proj_lds", "k_dwconv", "k_dw_tiled", "k_dw3_", "k_se", "k_fused",
               "k_mbconv_block", "k_sweep_mbconv",
               "k_win_attn", "k_layernorm", "k_patch_embed", "k_ln_token_mean")
 
 
 def family(name: str) -> str:
-    if "k_gemm" in name or "k_proj_lds" in name or "k_splitk_reduce" in name:
+    if "k_gemm" in name or "k_proj_lds" in name or "k_splitk_reduce" in name or "k_head_gap" in name:
         return "gemm"
     if "k_mbconv_block" in name:
         return "block"
