@@ -1188,6 +1188,11 @@ int launch_gemm_bf16(const GemmArgs& a, hipStream_t st) {
         if (nch >= 2 && gemm_splitk_bytes(a.M, a.N, a.K) <= a.splitk_ws_bytes && (!a.gate || a.gate_ld % 4 == 0))
             return launch_splitk(a, nch, st);
     }
+    // Opt-in (MI355_GEMM_WIDE=1): the persistent 256-wide tile kernel (gemm_wide.hip), bit-identical to k_gemm_big on the same shape.
+    // Off by default: on Swin's linears it reaches 0.7 - 1.0x of k_gemm_big (profiles/r03_gemm_wide_ab.txt) - both are bound by the
+    // ~27 B/clk a CU takes in through LDS-DMA / stores (tools/dma_probe.hip), and the lock-step 8-wave tile exposes its epilogue.
+    const int use_wide = getenv("MI355_GEMM_WIDE") ? atoi(getenv("MI355_GEMM_WIDE")) : 0;   // (read per call: tools / tests A/B it in one process)
+    if (use_wide && gemm_wide_supported(a)) return launch_gemm_wide(a, st);
     // Measured on MI355X (profiles/r01_effnet_per_op_*.txt): the 64-row / BK=64 variants lose to 128 x BN x 32
     // on every EfficientNet layer (each wave re-reads the whole W tile from LDS, so halving the rows per wave
     // makes the block LDS-bound); they stay instantiated for tiny-M problems (classifier, M = batch).

@@ -29,6 +29,9 @@ struct GemmArgs {
     const float* ln_colsum;  // [ceil16(N)] column sums of the (gamma-folded) weights
 };
 int launch_gemm_bf16(const GemmArgs& a, hipStream_t st);
+// persistent wide-tile kernel for the compute-bound linears (gemm_wide.hip); launch_gemm_bf16 routes the shapes it supports there
+bool gemm_wide_supported(const GemmArgs& a);
+int launch_gemm_wide(const GemmArgs& a, hipStream_t st);
 // Split-K for the tiny-M late projections (7x7 / 14x14 maps at small batch: a handful of output tiles, each with a serial
 // K loop of 20-70 L2 round trips).  Number of 256-deep K chunks the shape is split into, 0 = not a split-K shape.  The
 // decision looks at the layer (rows per image, K) and caps M, never at the batch position.

@@ -119,6 +119,55 @@ def test_short_k_gemm_instantiation_matches_the_default_one(N, act):
     assert err < 2.0 ** -7 * max(1.0, ref.abs().max().item()), err      # one bf16 rounding of the output
 
 
+@pytest.fixture
+def wide_gemm_env():
+    """MI355_GEMM_WIDE is read per call by launch_gemm_bf16; leave the process as it was found."""
+    import os
+    old = os.environ.get("MI355_GEMM_WIDE")
+    yield lambda v: os.environ.__setitem__("MI355_GEMM_WIDE", v)
+    if old is None:
+        os.environ.pop("MI355_GEMM_WIDE", None)
+    else:
+        os.environ["MI355_GEMM_WIDE"] = old
+
+
+@pytest.mark.parametrize("Mm,N,K,act", [(25088, 512, 512, 0), (6272, 1024, 2048, 4), (5000, 520, 192, 1), (4100, 264, 128, 0)])
+def test_wide_tile_gemm_has_the_bits_of_the_128_tile(wide_gemm_env, Mm, N, K, act):
+    """The opt-in persistent 256-wide kernel (csrc/gemm_wide.hip) sums every output's k-steps in the order k_gemm_big does, through
+    the same MFMA: interior tiles, ragged last row / column tiles, several tiles per workgroup, every activation epilogue."""
+    from imageretrievalresearch_amd._lib import lib, check, stream_ptr
+    g = torch.Generator(device="cpu").manual_seed(Mm + N)
+    A = (torch.randn(Mm, K, generator=g) * 0.5).to(DEV).bfloat16()
+    Np = (N + 15) // 16 * 16
+    W = torch.zeros(Np, K, device=DEV, dtype=torch.bfloat16)
+    W[:N] = (torch.randn(N, K, generator=g) * 0.1).to(DEV).bfloat16()
+    bias = torch.zeros(Np, device=DEV)
+    bias[:N] = torch.randn(N, generator=g).to(DEV) * 0.1
+    outs = []
+    for mode in ("0", "1"):
+        wide_gemm_env(mode)
+        out = torch.full((Mm, N), 3.0, device=DEV, dtype=torch.bfloat16)
+        check(lib().mi355_gemm_bf16(A.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr(), Mm, N, K, K, act, stream_ptr(DEV)))
+        outs.append(out)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    ref = A.float() @ W[:N].float().t() + bias[:N]
+    ref = {0: lambda t: t, 1: torch.nn.functional.silu, 4: torch.nn.functional.gelu}[act](ref)
+    assert (outs[1].float() - ref).abs().max().item() < 2.0 ** -7 * max(1.0, ref.abs().max().item())
+
+
+def test_swin_forward_through_the_wide_tile_gemm_is_bit_identical(wide_gemm_env):
+    """B = 32: stages 1-3 have >= 4096 token rows, so qkv (folded LayerNorm), proj (+ residual), fc1 (folded LayerNorm + GELU) and
+    fc2 (+ residual) of 22 blocks and the patch-merging reductions run through k_gemm_wide: the embedding must not move by a bit."""
+    from imageretrievalresearch_amd import synth
+    model = M.create_model("swin_base_patch4_window7_224", num_classes=0, seed=6).to(DEV).eval()
+    x = M.synth_fill(32 * 3 * 224 * 224, 91, synth.UNIFORM, DEV).view(32, 3, 224, 224)
+    wide_gemm_env("0")
+    a = model(x).clone()
+    wide_gemm_env("1")
+    b = model(x).clone()
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
 def test_layernorm_folded_into_the_gemm_agrees_with_the_separate_kernel():
     """B = 24: every stage has >= 1024 token rows, so all 48 norm1 / norm2 LayerNorms run as a (mean, rstd) pass plus the
     consumer GEMM's epilogue  rstd (x W'^T - mean colsum(W')) + b'  with gamma folded into W' and beta into b'.  Against the
