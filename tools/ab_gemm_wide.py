@@ -13,6 +13,9 @@ shapes = [(25088, 1536, 512), (25088, 2048, 512), (25088, 512, 2048), (25088, 51
 if len(sys.argv) > 1:
     shapes = [tuple(int(v) for v in t.split("x")) for t in sys.argv[1].split(",")]
 act = int(os.environ.get("ACT", "4"))
+VAR = os.environ.get("AB_VAR", "MI355_GEMM_WIDE")      # the switch to A/B: MI355_GEMM_WIDE or MI355_GEMM_BN256
+BASE = {"MI355_GEMM_WIDE": "0", "MI355_GEMM_BN256": "0"}
+for k_, v_ in BASE.items(): os.environ[k_] = v_
 for (Mm, N, K) in shapes:
     ldw = (K + 31) // 32 * 32
     Np = (N + 15) // 16 * 16
@@ -23,7 +26,7 @@ for (Mm, N, K) in shapes:
     bias = torch.randn(Np, device=dev, generator=g) * 0.1
     outs, times = {}, {}
     for mode in ("0", "1"):
-        os.environ["MI355_GEMM_WIDE"] = mode
+        os.environ[VAR] = mode
         out = torch.full((Mm, N), 7.0, device=dev, dtype=torch.bfloat16)
         def run():
             check(lib().mi355_gemm_bf16(A.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr(), Mm, N, K, ldw, act, stream_ptr(dev)))
@@ -39,5 +42,5 @@ for (Mm, N, K) in shapes:
     same = torch.equal(outs["0"].view(torch.int16), outs["1"].view(torch.int16))
     nbad = int((outs["0"].view(torch.int16) != outs["1"].view(torch.int16)).sum())
     tf = lambda ms: 2.0 * Mm * N * K / ms / 1e9
-    print(f"M={Mm:7d} N={N:5d} K={K:5d}  big {times['0']*1e3:7.1f} us {tf(times['0']):6.0f} TF | wide {times['1']*1e3:7.1f} us {tf(times['1']):6.0f} TF"
+    print(f"M={Mm:7d} N={N:5d} K={K:5d}  off {times['0']*1e3:7.1f} us {tf(times['0']):6.0f} TF | on {times['1']*1e3:7.1f} us {tf(times['1']):6.0f} TF"
           f" | x{times['0']/times['1']:.2f}  bits {'identical' if same else f'DIFFER in {nbad}'}", flush=True)
