@@ -518,7 +518,7 @@ typedef __bf16 dw_bf16x8 __attribute__((ext_vector_type(8)));
 // output pixels through LDS as one contiguous 32*C*2-byte run.  No barriers: a wave only touches its own LDS region, and
 // the LDS executes one wave's instructions in order.  The next tile's loads are requested before this tile's MFMAs.
 template <int NU>
-__global__ __launch_bounds__(256, NU >= 4 ? 3 : 4) void k_dw3_lds(
+__global__ __launch_bounds__(256, NU >= 6 ? 2 : (NU >= 4 ? 3 : 4)) void k_dw3_lds(
     const bf16_t* __restrict__ in, const bf16_t* __restrict__ w, const float* __restrict__ bias, bf16_t* __restrict__ out,
     float* __restrict__ pool_partial, int B, int nblk, int H, int W, int act, unsigned magicW, int tiles_per_wg) {
     constexpr int C = NU * 8, PB = C * 2;                 // channels (the whole layer), bytes per pixel
@@ -670,10 +670,10 @@ int launch_dwconv(const bf16_t* in, const bf16_t* w, const float* bias, bf16_t* 
         return PX == 7 ? launch_dw_tiled<5, 7>(in, w, bias, out, pool_partial, B, H, W, C, TH, CGC, lds, act, pool_nblk, st)
                        : launch_dw_tiled<5, 4>(in, w, bias, out, pool_partial, B, H, W, C, TH, CGC, lds, act, pool_nblk, st);
     }
-    // narrow 3x3 stride-1 layers (C <= 40): matrix-pipe kernel with wave-private LDS staging (C40 @112x112: 0.218 -> 0.126 ms);
+    // narrow 3x3 stride-1 layers (C <= 48): matrix-pipe kernel with wave-private LDS staging (C40 @112x112: 0.218 -> 0.126 ms);
     // MI355_DW_MFMA=0 keeps the direct kernel
     static const int use_mfma = getenv("MI355_DW_MFMA") ? atoi(getenv("MI355_DW_MFMA")) : 1;
-    if (use_mfma && k == 3 && stride == 1 && C <= 40 && W % 2 == 0 && W >= 4 && (long)H * W * C * 2 < (1L << 30)) {
+    if (use_mfma && k == 3 && stride == 1 && C <= 48 && W % 2 == 0 && W >= 4 && (long)H * W * C * 2 < (1L << 30)) {
         const int ntiles = cdiv((long)H * W, 32);
         int nb = std::min(std::min(dw_pool_blocks(Ho, Wo, C), 14), ntiles);      // <= the squeeze-partial slot the planner sized
         const int tpw = cdiv(ntiles, nb);
@@ -685,7 +685,8 @@ int launch_dwconv(const bf16_t* in, const bf16_t* w, const float* bias, bf16_t* 
             case 2: launch_dw3_lds<2>(in, w, bias, out, pool_partial, B, nb, H, W, act, magic, tpw, st); break;
             case 3: launch_dw3_lds<3>(in, w, bias, out, pool_partial, B, nb, H, W, act, magic, tpw, st); break;
             case 4: launch_dw3_lds<4>(in, w, bias, out, pool_partial, B, nb, H, W, act, magic, tpw, st); break;
-            default: launch_dw3_lds<5>(in, w, bias, out, pool_partial, B, nb, H, W, act, magic, tpw, st); break;
+            case 5: launch_dw3_lds<5>(in, w, bias, out, pool_partial, B, nb, H, W, act, magic, tpw, st); break;
+            default: launch_dw3_lds<6>(in, w, bias, out, pool_partial, B, nb, H, W, act, magic, tpw, st); break;   // (rexnet_150's C48 @112x112)
         }
         MI355_LAUNCH_CHECK();
         return OK;

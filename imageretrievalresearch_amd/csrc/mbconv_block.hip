@@ -68,6 +68,18 @@ __host__ __device__ static inline int mb_proj_ntw(int NTp, int MTp, int NTW) {
     return best;
 }
 
+// Column tiles per wave the launcher and the support check use: the best split with at most three (every shape of round 2);
+// 14x14 maps whose 13 ... 16 column tiles would then leave a wave more than `mwp` row tiles take four (4 x 2 waves of 7 row tiles).
+__host__ __device__ static inline int mb_pick_ntw(int NTp, int MTp, int wi, int mwp) {
+    const int ntw = mb_proj_ntw(NTp, MTp, 3);
+    if (wi != 14) return ntw;
+    const int nwn = (NTp + ntw - 1) / ntw;
+    int msplit = nwn <= MB_WAVES ? MB_WAVES / nwn : 1;
+    if (msplit > MTp) msplit = MTp;
+    if (nwn <= MB_WAVES && (MTp + msplit - 1) / msplit <= mwp) return ntw;
+    return 4;
+}
+
 // Tap pairs of the MFMA depthwise (phase 2): one 16x16x32 MFMA covers TWO taps x 16 channels of K.  Pairs are vertical
 // (ky, kx) + (ky+1, kx) for ky = 0, 2, .. and horizontal along the last row, so that the second tap of a pair is always
 // "+1 E row" or "+1 E pixel" from the first: the per-lane part of the LDS address is then one of two bases and the
@@ -842,13 +854,13 @@ static bool mb_geom(int H, int W, MbGeom* g) {
 // depthwise activation).  Every whole-block shape of the three model families at 224 x 224 is listed; anything else keeps the
 // unfused chain (a kernel of this size costs ~2 s of build time and ~40 KB of code object).
 //   efficientnet_b3a (SiLU after the depthwise conv): blocks 3.1-3.4 | 4.0 | 4.1-4.4 | 5.0 (stride 2) | 5.1-5.5 | 6.0 | 6.1
-//   rexnet_150 / rexnet_200 (linear depthwise, ReLU6 behind the SE gate, 3x3 only): 14x14 blocks 6-9 / 6-7, 7x7 blocks 12-15
+//   rexnet_150 / rexnet_200 (linear depthwise, ReLU6 behind the SE gate, 3x3 only): 14x14 blocks 6-10 / 6-8, 7x7 blocks 12-15
 #define MB_INSTANCES(X)                                                                                              \
     X(3, 1, 14, 3, 3, ACT_SILU) X(5, 1, 14, 3, 3, ACT_SILU) X(5, 1, 14, 5, 3, ACT_SILU) X(5, 2, 14, 5, 2, ACT_SILU)     \
     X(5, 1, 7, 8, 2, ACT_SILU) X(3, 1, 7, 8, 3, ACT_SILU) X(3, 1, 7, 12, 3, ACT_SILU)                                 \
     X(3, 1, 14, 4, 2, ACT_NONE) X(3, 1, 14, 4, 3, ACT_NONE) X(3, 1, 14, 5, 3, ACT_NONE) X(3, 1, 14, 6, 3, ACT_NONE)   \
     X(3, 1, 7, 7, 2, ACT_NONE) X(3, 1, 7, 8, 2, ACT_NONE) X(3, 1, 7, 8, 3, ACT_NONE) X(3, 1, 7, 9, 3, ACT_NONE)       \
-    X(3, 1, 7, 10, 3, ACT_NONE) X(3, 1, 7, 11, 3, ACT_NONE)
+    X(3, 1, 7, 10, 3, ACT_NONE) X(3, 1, 7, 11, 3, ACT_NONE) X(3, 1, 14, 6, 4, ACT_NONE)
 static bool mb_instance_ok(int k, int stride, int wi, int kst, int ntw, int act_d) {
 #define X(KS, S, WI, KST, NTW, AD) if (k == KS && stride == S && wi == WI && kst == KST && ntw == NTW && act_d == AD) return true;
     MB_INSTANCES(X)
@@ -923,7 +935,7 @@ bool mbconv_block_supported(int H, int W, int Cin, int mid, int Cout, int k, int
     const int pad = k / 2;
     a.Ho = (H + 2 * pad - k) / stride + 1; a.Wo = (W + 2 * pad - k) / stride + 1;
     const int Pout = a.Ho * a.Wo, MTp = (Pout + 15) / 16, NTp = (Cout + 15) / 16;
-    const int ntw = mb_proj_ntw(NTp, MTp, g.ntw);
+    const int ntw = mb_pick_ntw(NTp, MTp, g.wi, g.mwp);
     const int nwn = (NTp + ntw - 1) / ntw;
     if (nwn > MB_WAVES) return false;
     int msplit = MB_WAVES / nwn;
@@ -959,7 +971,9 @@ static int launch_mb(BlockArgs a, int B, hipStream_t st) {
 int launch_mbconv_block(const BlockArgs& a, int B, int k, int stride, hipStream_t st) {
     MI355_REQUIRE(mbconv_block_supported(a.H, a.W, a.Cin, a.mid, a.Cout, k, stride, a.rd, a.act_e, a.act_d), "mbconv_block: unsupported shape");
     const int Pout = a.Ho * a.Wo;
-    const int ntw = mb_proj_ntw((a.Cout + 15) / 16, (Pout + 15) / 16, 3);      // column tiles per wave of the projection (the kernel's NTW is exact)
+    MbGeom gg;
+    mb_geom(a.H, a.W, &gg);
+    const int ntw = mb_pick_ntw((a.Cout + 15) / 16, (Pout + 15) / 16, gg.wi, gg.mwp);   // column tiles per wave of the projection (the kernel's NTW is exact)
     const int kst = a.Kp / 32;
 #define X(KS, S, WI, KST, NTW, AD)                                                                  \
     if (k == KS && stride == S && a.W == WI && kst == KST && ntw == NTW && a.act_d == AD)           \
