@@ -331,7 +331,7 @@ static int exec_op(ExecCtx& cx, const Op& op) {
 
 // row-sweep kernel (MFMA depthwise, complete squeeze sums): the early-stage shape classes of sweep_mbconv.hip
 static bool use_sweep(const mi355_model* m, const Op& g, const Op& d, int h, int w) {
-    return m->fuse_sweep && sweep_mbconv_supported(h, w, g.cin, g.cout, d.k, d.stride);
+    return m->fuse_sweep && sweep_mbconv_supported(h, w, g.cin, g.cout, d.k, d.stride, g.act, d.act);
 }
 
 // expand GEMM (-> SLOT_E) immediately followed by the depthwise conv that consumes it, on a whole-image tile

@@ -74,7 +74,7 @@ struct SweepArgs {
     int debug_skip;       // diagnosis only: bit0 skip the expand phase, bit1 skip the depthwise phase, bit2 skip the X loads
     long long* stamps;    // diagnosis only: [B][16] cycle buckets, summed over the image's workgroups (wave 0's view)
 };
-bool sweep_mbconv_supported(int H, int W, int Cin, int mid, int k, int stride);
+bool sweep_mbconv_supported(int H, int W, int Cin, int mid, int k, int stride, int act_e, int act_d);
 int launch_sweep_mbconv(const SweepArgs& a, int B, int k, int stride, hipStream_t st);
 
 // ---- whole MBConv block for the late stages (mbconv_block.hip): expand -> depthwise -> SE -> gated projection (+ residual)

@@ -85,7 +85,7 @@ struct SwGeom {
     }
 };
 
-// One 16-channel slab at a time; NW waves split the 16-pixel tiles of both phases; KST = Kp / 32 (1 or 2); OCC = workgroups
+// One 16-channel slab at a time; NW waves split the 16-pixel tiles of both phases; KST = Kp / 32 (1 ... 4); OCC = workgroups
 // the host expects per CU (register budget); PREF: request the next band's X fragments before the depthwise phase.
 //
 // Per band ONE barrier: the E rows live in two buffers used alternately, so a wave that finishes the depthwise phase of
@@ -362,7 +362,7 @@ struct SwPlan { int cls; int wgs_per_cu; int nct; };
 
 // shape classes (template instances).  NCT = 1 everywhere: one 16-channel tile per slab keeps the row buffer <= 55 KB
 // (2-3 workgroups per CU); 7 waves because 49 pixel tiles (14 or 28 rows of 56 / 28 pixels) split evenly over them.
-enum { SW_NONE = 0, SW_3_2_112, SW_3_1_56, SW_5_2_56, SW_5_1_28, SW_3_2_28 };
+enum { SW_NONE = 0, SW_3_2_112, SW_3_1_56, SW_5_2_56, SW_5_1_28, SW_3_2_28, SW_3_2_56, SW_3_1_28 };
 
 static int sw_class(int H, int W, int k, int stride) {
     if (k == 3 && stride == 2 && W == 112 && H == 112) return SW_3_2_112;
@@ -370,12 +370,25 @@ static int sw_class(int H, int W, int k, int stride) {
     if (k == 5 && stride == 2 && W == 56 && H == 56) return SW_5_2_56;
     if (k == 5 && stride == 1 && W == 28 && H == 28) return SW_5_1_28;
     if (k == 3 && stride == 2 && W == 28 && H == 28) return SW_3_2_28;
+    if (k == 3 && stride == 2 && W == 56 && H == 56) return SW_3_2_56;
+    if (k == 3 && stride == 1 && W == 28 && H == 28) return SW_3_1_28;
     return SW_NONE;
 }
 
-bool sweep_mbconv_supported(int H, int W, int Cin, int mid, int k, int stride) {
-    if (Cin % 8 || mid % 8 || Cin > 64 || Cin < 8) return false;
-    return sw_class(H, W, k, stride) != SW_NONE;
+// RexNet's squeeze-excite blocks at 56x56 / 28x28 (SiLU after the expand, linear depthwise; 58 ... 122 input channels = two to four
+// k-steps): (class, k-steps) pairs that exist for exactly that activation pair
+static bool sw_rex_instance(int cls, int kst) {
+    // (measured, B = 256: 77->462 s2 @56 0.57 -> 0.42 ms, 58->348 0.40 -> 0.35, 75->450 @28 0.20 -> 0.16, 100->600 0.28 -> 0.26, 92->552 s2 0.18 -> 0.16;
+    //  122->732 s2 @28 with four k-steps LOST, 0.23 -> 0.39 ms (11 spilled registers in the expand loop): not instantiated)
+    return (cls == SW_3_2_56 && (kst == 2 || kst == 3)) || (cls == SW_3_1_28 && (kst == 3 || kst == 4)) || (cls == SW_3_2_28 && kst == 3);
+}
+
+bool sweep_mbconv_supported(int H, int W, int Cin, int mid, int k, int stride, int act_e, int act_d) {
+    if (Cin % 8 || mid % 8 || Cin < 8) return false;
+    const int cls = sw_class(H, W, k, stride), kst = (Cin + 31) / 32;
+    if (cls == SW_NONE) return false;
+    if (act_e == ACT_SILU && act_d == ACT_NONE && sw_rex_instance(cls, kst)) return true;
+    return Cin <= 64 && cls <= SW_3_2_28;
 }
 
 template <int KS, int S, int WI, int TH, int NW, int KST, int OCC, bool PREF, int AE, int AD>
@@ -421,11 +434,19 @@ static int launch_sw(const SweepArgs& a, int B, hipStream_t st) {
     return launch_sw_act<KS, S, WI, TH, NW, KST, OCC, PREF, ACT_SILU, ACT_SILU>(a, B, st)
 
 int launch_sweep_mbconv(const SweepArgs& a, int B, int k, int stride, hipStream_t st) {
-    MI355_REQUIRE(sweep_mbconv_supported(a.H, a.W, a.Cin, a.mid, k, stride) && (a.Kp == 32 || a.Kp == 64),
+    MI355_REQUIRE(sweep_mbconv_supported(a.H, a.W, a.Cin, a.mid, k, stride, a.act_e, a.act_d) && a.Kp % 32 == 0 && a.Kp >= 32 && a.Kp <= 128,
                   "sweep_mbconv: unsupported shape %dx%d k%d s%d Cin %d", a.H, a.W, k, stride, a.Cin);
     const bool k2 = a.Kp == 64;
     const bool silu = a.act_e == ACT_SILU && a.act_d == ACT_SILU;
     const int cls = sw_class(a.H, a.W, k, stride);
+    if (a.act_e == ACT_SILU && a.act_d == ACT_NONE && sw_rex_instance(cls, a.Kp / 32)) {
+#define SW_REX(KS, S, WI, TH, NW, KST, OCC) return launch_sw_act<KS, S, WI, TH, NW, KST, OCC, false, ACT_SILU, ACT_NONE>(a, B, st)
+        if (cls == SW_3_2_56) { if (a.Kp == 64) SW_REX(3, 2, 56, 2, 7, 2, 2); SW_REX(3, 2, 56, 2, 7, 3, 2); }
+        if (cls == SW_3_1_28) { if (a.Kp == 96) SW_REX(3, 1, 28, 4, 7, 3, 2); SW_REX(3, 1, 28, 4, 7, 4, 2); }
+        SW_REX(3, 2, 28, 4, 7, 3, 2);
+#undef SW_REX
+    }
+    MI355_REQUIRE(a.Kp <= 64 && cls <= SW_3_2_28, "sweep_mbconv: no instance for %dx%d k%d s%d Kp %d", a.H, a.W, k, stride, a.Kp);
     const int v = (silu && k2 == (cls == SW_5_1_28 || cls == SW_3_2_28)) ? a.variant : 0;
     switch (cls) {
         case SW_3_2_112:
