@@ -873,11 +873,12 @@ static int launch_proj_cfg(const GemmArgs& a, hipStream_t st) {
 static int try_launch_proj(const GemmArgs& a, hipStream_t st) {
     // measured (EfficientNet-B3a B=256): 112x112 / 56x56 projections 0.111 -> 0.087, 0.135 -> 0.108, 0.082 -> 0.058, 0.105 -> 0.096 ms;
     // the 28x28 ones (M = 200k rows, K = 192 / 288: one workgroup per CU) lose 0.030 -> 0.039, 0.044 -> 0.057: large M only
-    if (a.out_f32 || a.M < (1 << 19) || a.N % 8 || a.ldo % 8 || a.N > 48 || a.K > 288 || a.lda != a.K) return -1;
+    if (a.out_f32 || a.M < (1 << 19) || a.N % 8 || a.ldo % 8 || a.N > 64 || a.K > 288 || a.lda != a.K) return -1;
     if (a.gate && (a.rows_per_img % 16 != 0 || a.gate_ld % 4 != 0)) return -1;
     const int kst = (a.K + 31) / 32, nt = (a.N + 15) / 16;
 #define PROJ_CASE(NTV, KSTV) if (nt == NTV && kst == KSTV) return launch_proj_cfg<NTV, KSTV>(a, st)
     PROJ_CASE(2, 1); PROJ_CASE(2, 2); PROJ_CASE(2, 5); PROJ_CASE(2, 6); PROJ_CASE(3, 6); PROJ_CASE(3, 9); PROJ_CASE(2, 9);
+    PROJ_CASE(4, 8); PROJ_CASE(3, 5);        // rexnet_150: 246->58 @56x56 (+ residual), 144->41 @56x56
 #undef PROJ_CASE
     return -1;
 }
