@@ -150,3 +150,25 @@ def test_each_rexnet_block_on_the_oracles_own_input(name, wm, B):
         del got
     model.enable_taps(False)
     print(f"{name} B={B}: worst isolated block {worst}")
+
+
+@pytest.mark.parametrize("name,B,mb", [("rexnet_150", 256, 100), ("rexnet_200", 120, 70)])
+def test_rexnet_chunking_does_not_change_the_bits(name, B, mb):
+    """Same rule as tests/test_effnet_gpu.py::test_chunking_does_not_change_the_bits, on RexNet's own kernel choices: the whole-block
+    kernel (from 96 images of the CALLER's batch), the row-sweep classes (shape only), the wave-private projection kernel (from 2^19
+    rows of the chunk - same k order as the tiled kernel, so the same bits) and the split-K projections.  Microbatches that straddle
+    the thresholds and two concurrent lanes must reproduce the unchunked forward exactly."""
+    from imageretrievalresearch_amd import synth
+    model = M.create_model(name, num_classes=0, seed=4).to(DEV).eval()
+    x = M.synth_fill(B * 3 * 224 * 224, 33, synth.UNIFORM, DEV).view(B, 3, 224, 224)
+    want = model(x).clone()
+    try:
+        model.set_option("microbatch", mb)
+        assert torch.equal(model(x), want)
+        model.set_option("microbatch", 0)
+        model.set_option("lanes", 2)
+        assert torch.equal(model(x), want)
+    finally:
+        model.set_option("microbatch", 0)
+        model.set_option("lanes", 1)
+

@@ -258,3 +258,24 @@ def test_each_swin_block_on_the_oracles_own_input(setup, B, fuse_ln):
         model.enable_taps(False)
         model.set_option("fuse_ln", 1)
     print(f"swin B={B} fuse_ln={fuse_ln}: worst isolated block {worst}")
+
+
+def test_swin_chunking_does_not_change_the_bits():
+    """B = 128 cut into microbatches of 48 (the short-K three-workgroup GEMM instantiation is chosen from 32 768 rows of the CHUNK:
+    56 x 56 tokens x 48 images qualify, the 32-image remainder does not; LayerNorm folding needs 1024 rows) and run as two lanes: the
+    GEMM instantiations share their k order, so the embedding must not move by a bit."""
+    from imageretrievalresearch_amd import synth
+    model = M.create_model("swin_base_patch4_window7_224", num_classes=0, seed=6).to(DEV).eval()
+    B = 128
+    x = M.synth_fill(B * 3 * 224 * 224, 87, synth.UNIFORM, DEV).view(B, 3, 224, 224)
+    want = model(x).clone()
+    try:
+        model.set_option("microbatch", 48)
+        assert torch.equal(model(x), want)
+        model.set_option("microbatch", 0)
+        model.set_option("lanes", 2)
+        assert torch.equal(model(x), want)
+    finally:
+        model.set_option("microbatch", 0)
+        model.set_option("lanes", 1)
+
