@@ -41,9 +41,9 @@ rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CY
 unset CASES
 cd $ROOT
 python tools/pmc_kernels.py --sha "$SHA" --note "tools/bench_rank.py with CASES=256x100000 (Q=256, G=100000, D=1536, k=3), rocprofv3 --pmc in separate passes; FETCH_SIZE is in KiB per dispatch, RAW (the gallery arrives as 64-byte-per-row LDS-DMA pieces: the x2 wide-read correction of fetch_bytes_corrected does not apply to it)" $OUT/pmc_rank_fetch $OUT/pmc_rank_sq > $OUT/${R}_pmc_rank_kernels.json 2> $OUT/pmc_rank.err
-# RexNet-200 and Swin-B: HBM traffic + pipe busy per kernel name
+# RexNet-150 / -200 and Swin-B: HBM traffic + pipe busy per kernel name
 cd /tmp
-for m in "rexnet_200 256 rexnet200" "swin_base_patch4_window7_224 128 swin_base"; do
+for m in "rexnet_150 256 rexnet150" "rexnet_200 256 rexnet200" "swin_base_patch4_window7_224 128 swin_base"; do
   set -- $m
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_$3_fetch -- python3 $ROOT/tools/pmc_run.py $1 $2 > $OUT/pmc_$3_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_$3_write -- python3 $ROOT/tools/pmc_run.py $1 $2 > $OUT/pmc_$3_write.log 2>&1
