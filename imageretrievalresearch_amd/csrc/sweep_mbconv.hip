@@ -439,6 +439,13 @@ int launch_sweep_mbconv(const SweepArgs& a, int B, int k, int stride, hipStream_
     const bool k2 = a.Kp == 64;
     const bool silu = a.act_e == ACT_SILU && a.act_d == ACT_SILU;
     const int cls = sw_class(a.H, a.W, k, stride);
+    if (a.act_e == ACT_SILU && a.act_d == ACT_NONE && a.variant != 2 && a.Kp == 64 && (cls == SW_3_1_56 || cls == SW_3_2_56)) {
+        // RexNet's two-k-step layers at 56 x 56: one workgroup per CU (256 registers per wave) WITH the cross-phase X prefetch
+        // (rexnet_200 5.22 -> 5.11 ms, rexnet_150 level; the same trade LOSES on the three- and four-k-step instances: 5.06 -> 5.17;
+        //  sweep_variant 2 = the two-workgroup form without prefetch)
+        if (cls == SW_3_1_56) return launch_sw_act<3, 1, 56, 8, 8, 2, 1, true, ACT_SILU, ACT_NONE>(a, B, st);
+        return launch_sw_act<3, 2, 56, 2, 7, 2, 1, true, ACT_SILU, ACT_NONE>(a, B, st);
+    }
     if (a.act_e == ACT_SILU && a.act_d == ACT_NONE && sw_rex_instance(cls, a.Kp / 32)) {
 #define SW_REX(KS, S, WI, TH, NW, KST, OCC) return launch_sw_act<KS, S, WI, TH, NW, KST, OCC, false, ACT_SILU, ACT_NONE>(a, B, st)
         if (cls == SW_3_2_56) { if (a.Kp == 64) SW_REX(3, 2, 56, 2, 7, 2, 2); SW_REX(3, 2, 56, 2, 7, 3, 2); }
