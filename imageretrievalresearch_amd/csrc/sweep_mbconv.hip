@@ -79,7 +79,7 @@ struct SwGeom {
     static constexpr int WO = (WI + 2 * PAD - KS) / S + 1;
     static constexpr int ELD = 24;                            // 16 channels + 8: 16 pixels x 16 B land on distinct banks
     static constexpr int EBUF = (IH + 1) * RP * ELD;          // elements per buffer (+ one zero slack row: unused second taps)
-    static constexpr size_t lds_bytes(int nw) { return (size_t)2 * EBUF * 2 + (size_t)nw * 16 * 4; }
+    static constexpr size_t lds_bytes(int nw, int ns = 1) { return (size_t)ns * 2 * EBUF * 2 + (size_t)nw * 16 * ns * 4; }
     __host__ __device__ static constexpr int epx(int r, int c) {   // E pixel index of (buffer row, padded column)
         return r * RP + (S == 1 ? c : (c & 1) * EWH + (c >> 1));
     }
@@ -93,7 +93,10 @@ struct SwGeom {
 // and MFMA/LDS-heavy work of the same workgroup overlap.  The halo rows are copied buffer -> buffer at the start of the
 // depthwise phase.  "Band -1" is expand-only: it produces band 0's halo rows (zeros above the image), and rows below the
 // image are written as zeros by the same rule, so there is no separate zero-fill.
-template <int KS, int S, int WI, int TH, int NW, int KST, int OCC, bool PREF, int AE, int AD>
+// NS = 16-channel tiles per pass over the image (1, or 2: RexNet's layers with two or more k-steps of input channels were bound by
+// re-reading X from L2 once per tile - 22 passes over a 400 KB image at 6.5 TB/s; a pair of tiles per pass halves that, with the
+// E row windows, the slab constants and the squeeze sums held twice).
+template <int KS, int S, int WI, int TH, int NW, int KST, int OCC, bool PREF, int AE, int AD, int NS = 1>
 __global__ __launch_bounds__(NW * 64, (NW * OCC + 3) / 4) void k_sweep_mbconv(const SweepArgs a) {
     using G = SwGeom<KS, S, WI, TH>;
     using TP = SwTaps<KS>;
@@ -103,8 +106,8 @@ __global__ __launch_bounds__(NW * 64, (NW * OCC + 3) / 4) void k_sweep_mbconv(co
     constexpr int NPX2 = TH * WO, NT2 = (NPX2 + 15) / 16, MW2 = (NT2 + NW - 1) / NW;     // depthwise
     constexpr int EBUF = G::EBUF;
     extern __shared__ __attribute__((aligned(16))) unsigned char sw_smem[];
-    bf16_t* Es = reinterpret_cast<bf16_t*>(sw_smem);                                  // [2][EBUF]
-    float* red = reinterpret_cast<float*>(sw_smem + (size_t)2 * EBUF * 2);            // [NW][16]
+    bf16_t* Es = reinterpret_cast<bf16_t*>(sw_smem);                                  // [NS][2][EBUF]
+    float* red = reinterpret_cast<float*>(sw_smem + (size_t)NS * 2 * EBUF * 2);       // [NW][16 NS]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(NW * 64, (NW * OCC + 3) / 4) void k_sweep_mbconv(co
     const int b = xcd + 8 * (seq / a.csplit), g = seq % a.csplit;
     if (b >= a.B) return;
     const int midp = (a.mid + 15) & ~15;
-    const int nslab = midp / 16;
+    const int nslab = (midp / 16 + NS - 1) / NS;          // passes: NS channel tiles each
     const int nbands = (a.Ho + TH - 1) / TH;
 
     // optional phase timing (diagnosis): wave-uniform, the counters live in scalar registers
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(NW * 64, (NW * OCC + 3) / 4) void k_sweep_mbconv(co
     };
 
     // zero both buffers once: pad columns and the slack rows stay zero, the phases rewrite interior pixels only
-    for (int id = tid; id < 2 * EBUF / 8; id += NTHR) *reinterpret_cast<u32x4*>(&Es[id * 8]) = (u32x4){0u, 0u, 0u, 0u};
+    for (int id = tid; id < NS * 2 * EBUF / 8; id += NTHR) *reinterpret_cast<u32x4*>(&Es[id * 8]) = (u32x4){0u, 0u, 0u, 0u};
 
     // per-lane constants of the two tile loops (the same for every band and slab: no index arithmetic in the loops)
     int eoff[MW1];            // expand: E offset of this lane's pixel of tile i (row HALO + p / WI, 4 channels from fq * 4)
@@ -177,63 +180,74 @@ __global__ __launch_bounds__(NW * 64, (NW * OCC + 3) / 4) void k_sweep_mbconv(co
     // slabs are walked from an image-dependent start so co-resident workgroups do not stream the same weight lines in
     // lock-step (slabs are independent: no sum changes order)
     for (int si = g; si < nslab; si += a.csplit) {
-        const int ch0 = ((si + b) % nslab) * 16;
+        const int ch0 = ((si + b) % nslab) * (16 * NS);       // first channel of this pass; tile s covers ch0 + 16 s ...
         load_x(-1);
         // ---- slab constants: expand weights (MFMA A fragments) + bias, depthwise taps of this lane's channel + bias
-        u32x4 wf[KST];
-        {
-            const int n = min(ch0 + fr, midp - 1);
+        u32x4 wf[NS][KST];
+        f32x4 bb[NS], bdr[NS];
+        unsigned wd_raw[NS][(NP + 1) / 2];                    // two tap pairs per register
 #pragma unroll
-            for (int ks = 0; ks < KST; ++ks) wf[ks] = *reinterpret_cast<const u32x4*>(a.We + (n * a.Kp + ks * 32 + fk));
-        }
-        f32x4 bb = *reinterpret_cast<const f32x4*>(a.be + min(ch0 + fq * 4, midp - 4));
-        unsigned wd_raw[(NP + 1) / 2];                        // two tap pairs per register
-        {
-            const int ch = min(ch0 + fr, a.mid - 1);
+        for (int s = 0; s < NS; ++s) {
+            const int c0 = ch0 + 16 * s;
+            const int n = min(c0 + fr, midp - 1);
+#pragma unroll
+            for (int ks = 0; ks < KST; ++ks) wf[s][ks] = *reinterpret_cast<const u32x4*>(a.We + (n * a.Kp + ks * 32 + fk));
+            bb[s] = *reinterpret_cast<const f32x4*>(a.be + min(c0 + fq * 4, midp - 4));
+            const int ch = min(c0 + fr, a.mid - 1);
 #pragma unroll
             for (int tp = 0; tp < NP; ++tp) {
                 const int ta = TP::tap_a(tp), tb = TP::tap_b(tp) < 0 ? TP::tap_a(tp) : TP::tap_b(tp);
                 const unsigned v = a.Wd[((lane & 32) ? tb : ta) * a.mid + ch];
-                if (tp & 1) wd_raw[tp >> 1] |= v << 16;
-                else wd_raw[tp >> 1] = v;
+                if (tp & 1) wd_raw[s][tp >> 1] |= v << 16;
+                else wd_raw[s][tp >> 1] = v;
             }
+            bdr[s] = *reinterpret_cast<const f32x4*>(a.bd + min(c0 + fq * 4, a.mid - 4));
         }
-        f32x4 bdr = *reinterpret_cast<const f32x4*>(a.bd + min(ch0 + fq * 4, a.mid - 4));
         // diagonal weight fragments of the depthwise MFMAs: lane (n = lane & 15, kg = lane >> 4) holds k = kg*8 + j -> tap
         // (kg >> 1), channel (kg & 1)*8 + j of the tile: nonzero only where that channel is the lane's own n
-        auto build_dwf = [&](u32x4* dwf) {
-            const bool mine = ((fq & 1) == (fr >> 3)) && (ch0 + fr < a.mid);
+        auto build_dwf = [&](int s, u32x4* dwf) {
+            const bool mine = ((fq & 1) == (fr >> 3)) && (ch0 + 16 * s + fr < a.mid);
             const int q = (fr & 7) >> 1;
 #pragma unroll
             for (int tp = 0; tp < NP; ++tp) {
                 const bool has = mine && !((lane & 32) && TP::tap_b(tp) < 0);
-                const unsigned v = has ? ((tp & 1) ? wd_raw[tp >> 1] >> 16 : wd_raw[tp >> 1] & 0xffffu) : 0u;
+                const unsigned v = has ? ((tp & 1) ? wd_raw[s][tp >> 1] >> 16 : wd_raw[s][tp >> 1] & 0xffffu) : 0u;
                 const unsigned word = (fr & 1) ? (v << 16) : v;
                 dwf[tp] = (u32x4){q == 0 ? word : 0u, q == 1 ? word : 0u, q == 2 ? word : 0u, q == 3 ? word : 0u};
             }
         };
         constexpr bool DWF_PER_SLAB = KS == 3;               // 20 registers for 3x3; the 52 of 5x5 are rebuilt per band
-        u32x4 dwf_s[DWF_PER_SLAB ? NP : 1];
-        float psum[4] = {0.f, 0.f, 0.f, 0.f};
+        u32x4 dwf_s[NS][DWF_PER_SLAB ? NP : 1];
+        float psum[NS][4];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) psum[s][j] = 0.f;
         // retire the slab constants (and band -1's X fragments) HERE and pass them through an empty asm: hipcc then treats them
         // as plain register values.  Left alone it put a vmcnt(0) in front of the first depthwise MFMA of every band (first use
         // of the depthwise bias inside the loop), which also waited for the X fragments prefetched for the next band.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int ks = 0; ks < KST; ++ks) asm volatile("" : "+v"(wf[ks]));
-        asm volatile("" : "+v"(bb));
-        asm volatile("" : "+v"(bdr));
+        for (int s = 0; s < NS; ++s) {
 #pragma unroll
-        for (int i = 0; i < (NP + 1) / 2; ++i) asm volatile("" : "+v"(wd_raw[i]));
+            for (int ks = 0; ks < KST; ++ks) asm volatile("" : "+v"(wf[s][ks]));
+            asm volatile("" : "+v"(bb[s]));
+            asm volatile("" : "+v"(bdr[s]));
+#pragma unroll
+            for (int i = 0; i < (NP + 1) / 2; ++i) asm volatile("" : "+v"(wd_raw[s][i]));
+        }
 #pragma unroll
         for (int i = 0; i < MW1; ++i)
 #pragma unroll
             for (int ks = 0; ks < KST; ++ks) asm volatile("" : "+v"(xa[i][ks]));
-        if constexpr (DWF_PER_SLAB) build_dwf(dwf_s);
+        if constexpr (DWF_PER_SLAB) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) build_dwf(s, dwf_s[s]);
+        }
         tick(1);
 
         for (int band = -1; band < nbands; ++band) {
-            bf16_t* Ec = Es + ((band + 1) & 1) * EBUF;         // this band's buffer
+            bf16_t* Ec = Es + ((band + 1) & 1) * EBUF;         // this band's buffer of tile 0 (tile s: + s * 2 * EBUF)
             // ---- expand: rows [HALO, IH) of Ec = act(X W^T + b) for the band's new input rows, zeros outside the image
             {
                 const int iyn0 = band * NEWR - PAD + HALO;                       // first new input row
@@ -246,22 +260,25 @@ __global__ __launch_bounds__(NW * 64, (NW * OCC + 3) / 4) void k_sweep_mbconv(co
                     const int t0 = (wave + NW * i) * 16;
                     // (t0 < NPX1 is compile-time for all but the last i; band -1 only matters for the rows that become band 0's halo)
                     if (t0 < NPX1 && (band >= 0 || t0 + 16 > (NEWR - HALO) * WI)) {
-                        u32x2 o = {0u, 0u};
-                        if (t0 < phi && t0 + 16 > plo && !(a.debug_skip & 1)) {  // (wave-uniform) some pixel inside the image
-                            f32x4 acc = bb;
 #pragma unroll
-                            for (int ks = 0; ks < KST; ++ks)
-                                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wf[ks]),
-                                                                              *reinterpret_cast<bf16x8*>(&xa[i][ks]), acc, 0, 0, 0);
-                            acc.x = sw_act<AE>(acc.x, a.act_e); acc.y = sw_act<AE>(acc.y, a.act_e);
-                            acc.z = sw_act<AE>(acc.z, a.act_e); acc.w = sw_act<AE>(acc.w, a.act_e);
-                            o = sw_pack4(acc);
-                            if (t0 < plo || t0 + 16 > phi) {                     // (wave-uniform) tile straddles the image edge
-                                const bool in = t0 + fr >= plo && t0 + fr < phi;
-                                o.x = in ? o.x : 0u; o.y = in ? o.y : 0u;
+                        for (int s = 0; s < NS; ++s) {
+                            u32x2 o = {0u, 0u};
+                            if (t0 < phi && t0 + 16 > plo && !(a.debug_skip & 1)) {  // (wave-uniform) some pixel inside the image
+                                f32x4 acc = bb[s];
+#pragma unroll
+                                for (int ks = 0; ks < KST; ++ks)
+                                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&wf[s][ks]),
+                                                                                  *reinterpret_cast<bf16x8*>(&xa[i][ks]), acc, 0, 0, 0);
+                                acc.x = sw_act<AE>(acc.x, a.act_e); acc.y = sw_act<AE>(acc.y, a.act_e);
+                                acc.z = sw_act<AE>(acc.z, a.act_e); acc.w = sw_act<AE>(acc.w, a.act_e);
+                                o = sw_pack4(acc);
+                                if (t0 < plo || t0 + 16 > phi) {                     // (wave-uniform) tile straddles the image edge
+                                    const bool in = t0 + fr >= plo && t0 + fr < phi;
+                                    o.x = in ? o.x : 0u; o.y = in ? o.y : 0u;
+                                }
                             }
+                            if (t0 + fr < NPX1) *reinterpret_cast<u32x2*>(&Ec[s * 2 * EBUF + eoff[i]]) = o;
                         }
-                        if (t0 + fr < NPX1) *reinterpret_cast<u32x2*>(&Ec[eoff[i]]) = o;
                     }
                 }
                 if (PREF && band + 1 < nbands) load_x(band + 1);
@@ -273,23 +290,29 @@ __global__ __launch_bounds__(NW * 64, (NW * OCC + 3) / 4) void k_sweep_mbconv(co
             if (band + 1 < nbands) {
                 bf16_t* En = Es + (band & 1) * EBUF;
                 constexpr int NV16 = HALO * RP * ELD / 8;
-                for (int id = tid; id < NV16; id += NTHR)
-                    *reinterpret_cast<u32x4*>(&En[id * 8]) = *reinterpret_cast<const u32x4*>(&Ec[NEWR * RP * ELD + id * 8]);
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    for (int id = tid; id < NV16; id += NTHR)
+                        *reinterpret_cast<u32x4*>(&En[s * 2 * EBUF + id * 8]) = *reinterpret_cast<const u32x4*>(&Ec[s * 2 * EBUF + NEWR * RP * ELD + id * 8]);
             }
             tick(2);
             // ---- depthwise on the matrix pipe
-            if (band >= 0 && ch0 < a.mid && !(a.debug_skip & 2)) {      // (wave-uniform)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+            const int c0 = ch0 + 16 * s;
+            if (band >= 0 && c0 < a.mid && !(a.debug_skip & 2)) {      // (wave-uniform)
                 u32x4 dwf_b[DWF_PER_SLAB ? 1 : NP];
-                if constexpr (!DWF_PER_SLAB) build_dwf(dwf_b);
-                const u32x4* dwf = DWF_PER_SLAB ? dwf_s : dwf_b;
+                if constexpr (!DWF_PER_SLAB) build_dwf(s, dwf_b);
+                const u32x4* dwf = DWF_PER_SLAB ? dwf_s[s] : dwf_b;
                 const int np2 = min(TH, a.Ho - band * TH) * WO;
-                bf16_t* Dband = Db + band * NPX2 * a.mid + ch0 + fq * 4;
+                bf16_t* Dband = Db + band * NPX2 * a.mid + c0 + fq * 4;
+                const bf16_t* Ecs = Ec + s * 2 * EBUF;
 #pragma unroll
                 for (int i = 0; i < MW2; ++i) {
                     const int t0 = (wave + NW * i) * 16;
                     if (t0 < np2) {                                     // (wave-uniform)
-                        const bf16_t* ev = Ec + rbase[i] + vsel;
-                        const bf16_t* eh = Ec + rbase[i] + hsel;
+                        const bf16_t* ev = Ecs + rbase[i] + vsel;
+                        const bf16_t* eh = Ecs + rbase[i] + hsel;
                         auto e_read = [&](int tp) -> bf16x8 {
                             const int ta = TP::tap_a(tp);
                             const int offs = G::epx(ta / KS, ta % KS) * ELD;            // compile-time immediate after unrolling
@@ -300,7 +323,7 @@ __global__ __launch_bounds__(NW * 64, (NW * OCC + 3) / 4) void k_sweep_mbconv(co
 #pragma unroll
                         for (int k = 0; k < NB; ++k)
                             if (k < NP) ef[0][k] = e_read(k);
-                        f32x4 acc = bdr;
+                        f32x4 acc = bdr[s];
 #pragma unroll
                         for (int gq = 0; gq < NG; ++gq) {
                             if (gq + 1 < NG) {
@@ -319,13 +342,14 @@ __global__ __launch_bounds__(NW * 64, (NW * OCC + 3) / 4) void k_sweep_mbconv(co
                         acc.z = sw_act<AD>(acc.z, a.act_d); acc.w = sw_act<AD>(acc.w, a.act_d);
                         const int p = t0 + fr;
                         if (p < np2) {
-                            psum[0] += acc.x; psum[1] += acc.y; psum[2] += acc.z; psum[3] += acc.w;
-                            if (ch0 + fq * 4 < a.mid) {
+                            psum[s][0] += acc.x; psum[s][1] += acc.y; psum[s][2] += acc.z; psum[s][3] += acc.w;
+                            if (c0 + fq * 4 < a.mid) {
                                 *reinterpret_cast<u32x2*>(Dband + p * a.mid) = sw_pack4(acc);
                             }
                         }
                     }
                 }
+            }
             }
             tick(7);
         }
@@ -333,17 +357,21 @@ __global__ __launch_bounds__(NW * 64, (NW * OCC + 3) / 4) void k_sweep_mbconv(co
         // ---- squeeze: fold the 16 pixel lanes, then the waves, both in a fixed order
         if (a.pool) {
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
+            for (int s = 0; s < NS; ++s) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) psum[j] += __shfl_xor(psum[j], o, 64);
+                for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) psum[s][j] += __shfl_xor(psum[s][j], o, 64);
+                }
+                if (fr == 0) *reinterpret_cast<f32x4*>(&red[(wave * NS + s) * 16 + fq * 4]) = (f32x4){psum[s][0], psum[s][1], psum[s][2], psum[s][3]};
             }
-            if (fr == 0) *reinterpret_cast<f32x4*>(&red[wave * 16 + fq * 4]) = (f32x4){psum[0], psum[1], psum[2], psum[3]};
             sw_lds_barrier();
-            if (tid < 16) {
-                float s = 0.f;
+            if (tid < 16 * NS) {
+                const int s = tid >> 4, c = tid & 15;
+                float sum = 0.f;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) s += red[w * 16 + tid];
-                if (ch0 + tid < a.mid) a.pool[(size_t)b * a.mid + ch0 + tid] = s;
+                for (int w = 0; w < NW; ++w) sum += red[(w * NS + s) * 16 + c];
+                if (ch0 + tid < a.mid) a.pool[(size_t)b * a.mid + ch0 + tid] = sum;
             }
         }
         sw_lds_barrier();       // the next slab's band -1 rewrites the buffers (and red)
@@ -391,20 +419,21 @@ bool sweep_mbconv_supported(int H, int W, int Cin, int mid, int k, int stride, i
     return Cin <= 64 && cls <= SW_3_2_28;
 }
 
-template <int KS, int S, int WI, int TH, int NW, int KST, int OCC, bool PREF, int AE, int AD>
+template <int KS, int S, int WI, int TH, int NW, int KST, int OCC, bool PREF, int AE, int AD, int NS = 1>
 static int launch_sw_act(SweepArgs a, int B, hipStream_t st) {
     using G = SwGeom<KS, S, WI, TH>;
-    const size_t lds = G::lds_bytes(NW);
+    const size_t lds = G::lds_bytes(NW, NS);
+    static_assert(G::lds_bytes(NW, NS) <= 160 * 1024, "sweep: the row windows do not fit the LDS");
     static bool attr_done[MI355_MAX_DEVICES] = {false};   // per device
     if (first_time_on_this_device(attr_done)) {
-        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_sweep_mbconv<KS, S, WI, TH, NW, KST, OCC, PREF, AE, AD>,
+        MI355_CHECK_HIP(hipFuncSetAttribute((const void*)k_sweep_mbconv<KS, S, WI, TH, NW, KST, OCC, PREF, AE, AD, NS>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     // workgroups per image (each takes nslab / csplit slabs).  Measured at B = 256 (tools/tune_sweep.py): what matters is that the
     // slabs divide evenly (5 + 4 slabs per pair of workgroups cost 15 % against 3 + 3 + 3) and that a workgroup lives long
     // enough to amortise its start; the per-class preference below is the measured optimum, moved to the nearest divisor of
     // nslab, and raised for small batches until every CU slot has a workgroup.
-    const int nslab = cdiv(a.mid, 16);
+    const int nslab = cdiv(cdiv(a.mid, 16), NS);          // passes over the image: NS channel tiles each
     const int slots = 256 * OCC;
     int c = WI >= 56 ? (WI == 112 ? 3 : 4) : 2;
     while (c < nslab && (nslab % c != 0 || (long)B * c < slots)) ++c;
@@ -412,7 +441,7 @@ static int launch_sw_act(SweepArgs a, int B, hipStream_t st) {
     a.csplit = a.csplit_override > 0 ? std::min(a.csplit_override, nslab) : c;
     a.B = B;
     const unsigned grid = (unsigned)(8 * cdiv(B, 8) * a.csplit);
-    hipLaunchKernelGGL((k_sweep_mbconv<KS, S, WI, TH, NW, KST, OCC, PREF, AE, AD>), dim3(grid), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((k_sweep_mbconv<KS, S, WI, TH, NW, KST, OCC, PREF, AE, AD, NS>), dim3(grid), dim3(NW * 64), lds, st, a);
     MI355_LAUNCH_CHECK();
     return OK;
 }
@@ -439,19 +468,22 @@ int launch_sweep_mbconv(const SweepArgs& a, int B, int k, int stride, hipStream_
     const bool k2 = a.Kp == 64;
     const bool silu = a.act_e == ACT_SILU && a.act_d == ACT_SILU;
     const int cls = sw_class(a.H, a.W, k, stride);
-    if (a.act_e == ACT_SILU && a.act_d == ACT_NONE && a.variant != 2 && a.Kp == 64 && (cls == SW_3_1_56 || cls == SW_3_2_56)) {
-        // RexNet's two-k-step layers at 56 x 56: one workgroup per CU (256 registers per wave) WITH the cross-phase X prefetch
-        // (rexnet_200 5.22 -> 5.11 ms, rexnet_150 level; the same trade LOSES on the three- and four-k-step instances: 5.06 -> 5.17;
-        //  sweep_variant 2 = the two-workgroup form without prefetch)
-        if (cls == SW_3_1_56) return launch_sw_act<3, 1, 56, 8, 8, 2, 1, true, ACT_SILU, ACT_NONE>(a, B, st);
-        return launch_sw_act<3, 2, 56, 2, 7, 2, 1, true, ACT_SILU, ACT_NONE>(a, B, st);
-    }
-    if (a.act_e == ACT_SILU && a.act_d == ACT_NONE && sw_rex_instance(cls, a.Kp / 32)) {
-#define SW_REX(KS, S, WI, TH, NW, KST, OCC) return launch_sw_act<KS, S, WI, TH, NW, KST, OCC, false, ACT_SILU, ACT_NONE>(a, B, st)
-        if (cls == SW_3_2_56) { if (a.Kp == 64) SW_REX(3, 2, 56, 2, 7, 2, 2); SW_REX(3, 2, 56, 2, 7, 3, 2); }
-        if (cls == SW_3_1_28) { if (a.Kp == 96) SW_REX(3, 1, 28, 4, 7, 3, 2); SW_REX(3, 1, 28, 4, 7, 4, 2); }
-        SW_REX(3, 2, 28, 4, 7, 3, 2);
-#undef SW_REX
+    if (a.act_e == ACT_SILU && a.act_d == ACT_NONE && (sw_rex_instance(cls, a.Kp / 32) || (cls == SW_3_1_56 && a.Kp == 64))) {
+        // RexNet (SiLU after the expand, linear depthwise).  REX(class geometry..., k-steps, workgroups per CU, X prefetch, tiles per pass)
+#define REX(KS, S, WI, TH, NW, KST, OCC, PREF, NS) return launch_sw_act<KS, S, WI, TH, NW, KST, OCC, PREF, ACT_SILU, ACT_NONE, NS>(a, B, st)
+        const int kst = a.Kp / 32;
+        // measured at B = 256 (rexnet_150 / rexnet_200 forward): a pair of channel tiles per pass at 56 x 56 with one workgroup per CU:
+        // 41->246 0.35 -> 0.22 ms, 58->348 s2 0.35 -> 0.29, 54->324 0.46 -> 0.31, 77->462 s2 0.42 -> 0.41; the same at 28 x 28, and
+        // four-row bands for the stride-2 class, are level (and four-row bands change the order of the squeeze sums): not used
+        if (a.variant == 3) {      // tuning: one tile per pass at 56 x 56 as well
+            if (cls == SW_3_1_56) REX(3, 1, 56, 8, 8, 2, 1, true, 1);
+            if (cls == SW_3_2_56) { if (kst == 2) REX(3, 2, 56, 2, 7, 2, 1, true, 1); REX(3, 2, 56, 2, 7, 3, 2, false, 1); }
+        }
+        if (cls == SW_3_1_56) REX(3, 1, 56, 8, 8, 2, 1, true, 2);
+        if (cls == SW_3_2_56) { if (kst == 2) REX(3, 2, 56, 2, 7, 2, 1, true, 2); REX(3, 2, 56, 2, 7, 3, 1, false, 2); }
+        if (cls == SW_3_1_28) { if (kst == 3) REX(3, 1, 28, 4, 7, 3, 2, false, 1); REX(3, 1, 28, 4, 7, 4, 2, false, 1); }
+        REX(3, 2, 28, 4, 7, 3, 2, false, 1);
+#undef REX
     }
     MI355_REQUIRE(a.Kp <= 64 && cls <= SW_3_2_28, "sweep_mbconv: no instance for %dx%d k%d s%d Kp %d", a.H, a.W, k, stride, a.Kp);
     const int v = (silu && k2 == (cls == SW_5_1_28 || cls == SW_3_2_28)) ? a.variant : 0;
